@@ -1,0 +1,285 @@
+"""Known-answer tests that pin the CPU oracle: the reference has no
+tests or golden vectors for this path and g2o is not available, so the oracle is anchored by
+closed-form results instead."""
+import math
+
+import numpy as np
+import pytest
+
+PI = math.pi
+
+
+def rand_pose(rng, dim, scale=3.0):
+    if dim == 2:
+        return np.array([rng.normal(0, scale), rng.normal(0, scale), rng.uniform(-PI, PI)])
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    m = np.concatenate([rng.normal(0, scale, 3), q])
+    return m
+
+
+def test_normalize_theta(oracle):
+    O = oracle
+    assert O.normalize_theta(0.3) == 0.3
+    assert O.normalize_theta(PI) == pytest.approx(-PI)            # range is [-pi, pi)
+    assert O.normalize_theta(-PI) == -PI
+    assert O.normalize_theta(3 * PI + 0.1) == pytest.approx(-PI + 0.1)
+    assert O.normalize_theta(-7.0) == pytest.approx(-7.0 + 2 * PI)
+    for t in np.linspace(-20, 20, 101):
+        n = O.normalize_theta(t)
+        assert -PI <= n < PI
+        assert math.sin(n) == pytest.approx(math.sin(t), abs=1e-12)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_compose_inverse_roundtrip(oracle, dim):
+    O = oracle
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        A = O.meas_to_pose(dim, rand_pose(rng, dim))
+        B = O.meas_to_pose(dim, rand_pose(rng, dim))
+        I = O.pose_mul(dim, A, O.pose_inv(dim, A))
+        if dim == 2:
+            assert np.allclose(I, 0, atol=1e-12)
+        else:
+            assert np.allclose(I[:9].reshape(3, 3), np.eye(3), atol=1e-12)
+            assert np.allclose(I[9:], 0, atol=1e-12)
+        AB = O.pose_mul(dim, A, B)
+        B2 = O.pose_mul(dim, O.pose_inv(dim, A), AB)
+        assert np.allclose(B2, B, atol=1e-10)
+        # error of an exactly satisfied measurement is zero
+        e = O.edge_error(dim, B, A, AB)
+        assert np.allclose(e, 0, atol=1e-10)
+
+
+def test_se3_quaternion_sign_convention(oracle):
+    O = oracle
+    # a rotation by > pi about z: the normalised quaternion must come back with w >= 0
+    ang = 1.2 * PI
+    Z = O.meas_to_pose(3, [0, 0, 0, 0, 0, math.sin(ang / 2), math.cos(ang / 2)])
+    I = O.meas_to_pose(3, [0, 0, 0, 0, 0, 0, 1])
+    e = O.edge_error(3, I, I, Z)
+    # equivalent rotation -0.8*pi about z -> qz = sin(-0.4 pi)
+    assert e[5] == pytest.approx(math.sin(-0.4 * PI), abs=1e-12)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_jacobians_vs_finite_differences(oracle, dim):
+    O = oracle
+    rng = np.random.default_rng(2)
+    d = 3 if dim == 2 else 6
+    h = 1e-6
+    for trial in range(10):
+        Xi = O.meas_to_pose(dim, rand_pose(rng, dim))
+        rel = rand_pose(rng, dim, 1.0)
+        Xj = O.pose_mul(dim, Xi, O.meas_to_pose(dim, rel))
+        # measurement = relative pose perturbed, so the error is non-zero but moderate
+        pert = rng.normal(0, 0.2, d)
+        if dim == 3:
+            pert[3:] *= 0.5
+        Z = O.pose_oplus(dim, O.meas_to_pose(dim, rel), pert)
+        A, B = O.edge_jacobians(dim, Z, Xi, Xj)
+        An = np.zeros((d, d))
+        Bn = np.zeros((d, d))
+        for k in range(d):
+            dp = np.zeros(d)
+            dp[k] = h
+            ep = O.edge_error(dim, Z, O.pose_oplus(dim, Xi, dp), Xj)
+            em = O.edge_error(dim, Z, O.pose_oplus(dim, Xi, -dp), Xj)
+            An[:, k] = (ep - em) / (2 * h)
+            ep = O.edge_error(dim, Z, Xi, O.pose_oplus(dim, Xj, dp))
+            em = O.edge_error(dim, Z, Xi, O.pose_oplus(dim, Xj, -dp))
+            Bn[:, k] = (ep - em) / (2 * h)
+        assert np.allclose(A, An, atol=2e-6), (trial, A - An)
+        assert np.allclose(B, Bn, atol=2e-6), (trial, B - Bn)
+
+
+def _upper(M):
+    d = M.shape[0]
+    return np.array([M[i, j] for i in range(d) for j in range(i, d)])
+
+
+def _spd(rng, n, lo=20.0, hi=400.0):
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    return Q @ np.diag(rng.uniform(lo, hi, n)) @ Q.T
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_closed_form_single_loop_chi2(oracle, dim):
+    """Chain of L zero-motion odometry edges + one loop edge whose translation disagrees by
+    d: translation is then linear and decoupled from rotation, so with S = L*Cov_o/s + Cov_l
+    every odometry error is (Cov_o/s) S^-1 d, the loop error is -Cov_l S^-1 d (up to sign) and
+    the total chi2 is d^T S^-1 d.  (Rotation couples in at second order in |d| -- poses that
+    have moved apart can also turn -- so d is kept small and the tolerance is 1e-6.)"""
+    O = oracle
+    rng = np.random.default_rng(3 + dim)
+    L, s = 7, 10.0
+    td = dim                                     # translation dimension
+    d_tan = 3 if dim == 2 else 6
+    ms = 3 if dim == 2 else 7
+    ident = np.zeros(ms)
+    if dim == 3:
+        ident[6] = 1.0
+    Om_o_t = _spd(rng, td)
+    Om_l_t = _spd(rng, td)
+    Om_o = np.zeros((d_tan, d_tan)); Om_o[:td, :td] = Om_o_t; Om_o[td:, td:] = np.eye(d_tan - td) * 300
+    Om_l = np.zeros((d_tan, d_tan)); Om_l[:td, :td] = Om_l_t; Om_l[td:, td:] = np.eye(d_tan - td) * 200
+    odom_meas = np.tile(ident, (L, 1))
+    odom_info = np.tile(_upper(Om_o), (L, 1))
+    disc = rng.normal(0, 3e-4, td)
+    lm = ident.copy(); lm[:td] = disc
+    poses = O.propagate(dim, odom_meas)
+    r = O.solve_cell(dim, odom_meas, odom_info, s, poses, 0, L, [[0, L]], [lm], [_upper(Om_l)], 50)
+    Co = np.linalg.inv(Om_o_t) / s
+    Cl = np.linalg.inv(Om_l_t)
+    S = L * Co + Cl
+    w = np.linalg.solve(S, disc)
+    chi_total = disc @ w
+    e_o = Co @ w
+    e_l = Cl @ w
+    chi_o = e_o @ (s * Om_o_t) @ e_o
+    chi_l = e_l @ Om_l_t @ e_l
+    assert r["chi2_final"] == pytest.approx(chi_total, rel=1e-6)
+    assert np.allclose(r["chi2"][:L], chi_o, rtol=1e-6)
+    assert r["chi2"][L] == pytest.approx(chi_l, rel=1e-6)
+    assert r["max_chi2"] == pytest.approx(max(chi_o, chi_l), rel=1e-6)
+    assert chi_total == pytest.approx(L * chi_o + chi_l, rel=1e-9)
+
+
+def test_zero_residual_loop_and_threshold_flip(oracle):
+    O = oracle
+    L, s = 5, 10.0
+    ident = np.zeros(3)
+    Om = np.diag([100.0, 100.0, 400.0])
+    odom_meas = np.tile(ident, (L, 1))
+    odom_info = np.tile(_upper(Om), (L, 1))
+    poses = O.propagate(2, odom_meas)
+    r = O.solve_cell(2, odom_meas, odom_info, s, poses, 0, L, [[0, L]], [ident], [_upper(Om)], 50)
+    assert r["max_chi2"] == 0.0
+    # loop-edge chi2 as a function of the discrepancy scale a: chi_l = a^2 * c  (closed form)
+    Co = np.linalg.inv(Om[:2, :2]) / s
+    Cl = np.linalg.inv(Om[:2, :2])
+    S = L * Co + Cl
+    u = np.array([1.0, 0.0])
+    w = np.linalg.solve(S, u)
+    c_l = (Cl @ w) @ Om[:2, :2] @ (Cl @ w)
+    th = 6.251
+    a_star = math.sqrt(th / c_l)                 # loop edge crosses the threshold here
+    for a, expect in [(a_star * 0.999, True), (a_star * 1.001, False)]:
+        lm = np.array([a, 0.0, 0.0])
+        r = O.solve_cell(2, odom_meas, odom_info, s, poses, 0, L, [[0, L]], [lm], [_upper(Om)], 50)
+        assert (not (r["max_chi2"] > th)) == expect
+
+
+def _dense_gn(O, dim, odom_meas, odom_info, s, poses, lo, hi, loop_ids, loop_meas, loop_info, iters=60):
+    """Independent solver: dense Levenberg-Marquardt in numpy over the oracle's edge functions."""
+    d = 3 if dim == 2 else 6
+    L = hi - lo
+    X = [poses[lo + p].copy() for p in range(L + 1)]
+    edges = []
+    full = lambda u: (lambda M: M + M.T - np.diag(np.diag(M)))(  # noqa: E731
+        np.array([[u[sum(d - r for r in range(i)) + (j - i)] if j >= i else 0.0 for j in range(d)] for i in range(d)]))
+    for j in range(L):
+        edges.append((j, j + 1, O.meas_to_pose(dim, odom_meas[lo + j]), full(odom_info[lo + j]) * s))
+    for k, (a, b) in enumerate(loop_ids):
+        edges.append((a - lo, b - lo, O.meas_to_pose(dim, loop_meas[k]), full(loop_info[k])))
+
+    def chi(Xs):
+        return [float(O.edge_error(dim, Z, Xs[f], Xs[t]) @ Om @ O.edge_error(dim, Z, Xs[f], Xs[t]))
+                for f, t, Z, Om in edges]
+
+    lam = 1e-6
+    cur = sum(chi(X))
+    for _ in range(iters):
+        H = np.zeros((d * L, d * L)); b = np.zeros(d * L)
+        for f, t, Z, Om in edges:
+            e = O.edge_error(dim, Z, X[f], X[t])
+            A, B = O.edge_jacobians(dim, Z, X[f], X[t])
+            for (p, Jp) in ((f, A), (t, B)):
+                if p == 0:
+                    continue
+                b[d * (p - 1):d * p] -= Jp.T @ Om @ e
+                for (q, Jq) in ((f, A), (t, B)):
+                    if q == 0:
+                        continue
+                    H[d * (p - 1):d * p, d * (q - 1):d * q] += Jp.T @ Om @ Jq
+        h = np.linalg.solve(H + lam * np.eye(d * L), b)
+        Xn = [X[0]] + [O.pose_oplus(dim, X[p], h[d * (p - 1):d * p]) for p in range(1, L + 1)]
+        new = sum(chi(Xn))
+        if new < cur:
+            X, cur, lam = Xn, new, max(lam / 10, 1e-12)
+        else:
+            lam *= 10
+        if np.linalg.norm(h) < 1e-13:
+            break
+    return chi(X)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_solver_independence_on_fixture(oracle, dim):
+    """Dog-leg + skyline Cholesky must land on the same minimum as an independent dense LM."""
+    from ipc_amd import synth
+    O = oracle
+    g = synth.small_se2() if dim == 2 else synth.small_se3()
+    s = 10.0 if dim == 2 else 50.0
+    poses = O.propagate(dim, g.odom_meas)
+    for (i, j) in [(0, 0), (1, 1), (0, 1), (2, 3)]:
+        ids = g.loop_ids[[i]] if i == j else g.loop_ids[[i, j]]
+        lm = g.loop_meas[[i]] if i == j else g.loop_meas[[i, j]]
+        li = g.loop_info[[i]] if i == j else g.loop_info[[i, j]]
+        lo, hi = int(ids.min()), int(ids.max())
+        r = O.solve_cell(dim, g.odom_meas, g.odom_info, s, poses, lo, hi, ids, lm, li, 100)
+        ref = _dense_gn(O, dim, g.odom_meas, g.odom_info, s, poses, lo, hi, ids, lm, li)
+        # the total is second-order in the distance to the minimum, per-edge values first-order
+        assert r["chi2_final"] == pytest.approx(sum(ref), rel=1e-10), (i, j)
+        assert np.allclose(r["chi2"], ref, rtol=2e-6, atol=1e-10), (i, j)
+
+
+def test_interval_overlap_rule_and_order(oracle):
+    """computeIndependentSubgraph (consensus.cpp:157-159): touching intervals (overlap == 0)
+    are independent; cmpTime order with the (max id, index) tie-break."""
+    from ipc_amd import synth
+    O = oracle
+    g = synth.small_se2()
+    V = g.V
+    ident = np.zeros(3)
+    # perfect loops (zero residual): all accepted, so cluster bookkeeping is what is tested
+    poses = O.propagate(2, g.odom_meas)
+
+    def perfect(a, b):
+        rel = O.pose_mul(2, O.pose_inv(2, poses[a]), poses[b])
+        return rel
+
+    ids = np.array([[2, 10], [10, 20], [5, 12], [30, 40], [19, 31]], dtype=np.int32)
+    meas = np.array([perfect(a, b) for a, b in ids])
+    info = np.tile(g.loop_info[0], (len(ids), 1))
+    order = O.candidate_order(ids)
+    assert list(order) == [0, 2, 1, 4, 3]
+    ipc = O.IncrementalIPC(2, g.odom_meas, g.odom_info, 10.0, 6.251, 50, 11.345, 100, ids, meas, info)
+    ok, inf = ipc.agreement_check(0)
+    assert ok and (inf["lo"], inf["hi"], inf["cluster"]) == (2, 10, 0)
+    ok, inf = ipc.agreement_check(1)             # [10,20] touches [2,10]: NOT overlapping
+    assert ok and (inf["lo"], inf["hi"], inf["cluster"]) == (10, 20, 0)
+    ok, inf = ipc.agreement_check(2)             # [5,12] overlaps both -> transitive union
+    assert ok and (inf["lo"], inf["hi"], inf["cluster"]) == (2, 20, 2)
+    ok, inf = ipc.agreement_check(3)
+    assert ok and inf["cluster"] == 0
+    ok, inf = ipc.agreement_check(4)             # [19,31] overlaps [10,20] and [30,40]; chain pulls in all
+    assert ok and (inf["lo"], inf["hi"], inf["cluster"]) == (2, 40, 4)
+    assert list(ipc.consensus()) == [0, 1, 2, 3, 4]
+    # tie-break: equal max id -> file index
+    ids2 = np.array([[3, 9], [1, 9], [4, 7]], dtype=np.int32)
+    assert list(O.candidate_order(ids2)) == [2, 0, 1]
+    assert V > 40
+
+
+def test_set_max_is_greedy_clique(oracle):
+    O = oracle
+    ok = np.array([[1, 1, 0, 1],
+                   [1, 1, 1, 1],
+                   [0, 1, 1, 1],
+                   [1, 1, 1, 0]], dtype=np.uint8)
+    acc = O.set_max(ok, np.array([0, 1, 2, 3], dtype=np.int32))
+    assert list(acc) == [1, 1, 0, 0]              # 2 conflicts with 0; 3 fails its own diagonal
+    acc = O.set_max(ok, np.array([2, 1, 0, 3], dtype=np.int32))
+    assert list(acc) == [0, 1, 1, 0]
