@@ -1,0 +1,133 @@
+/*
+ * ipc_amd.h -- C ABI of the MI355X-native IPC consistency engine (libipc_amd.so).
+ *
+ * Drop-in boundary for the hot path of EmilioOlivastri/IPC: everything the reference does
+ * between "here is the odometry chain + the loop-closure candidates" and "this candidate set
+ * is consistent".  Each entry point names the reference interface it replaces (file:line in
+ * the reference tree).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ipc_status on failure, never throws,
+ *     never aborts; ipc_last_error() returns a human-readable message for the calling thread.
+ *   - measurements / information matrices use the g2o text-file layout the reference loads
+ *     (src/utils.cpp:114): SE2 "x y theta" + 6 upper-triangular information values;
+ *     SE3 "x y z qx qy qz qw" + 21 upper-triangular values in (x y z qx qy qz) order.
+ *   - vertex ids are 0..V-1 and odometry edge j joins vertex j -> j+1 (the reference's own
+ *     contract, src/consensus.cpp:13-23).
+ *   - pointers named d_* are DEVICE pointers (HBM of the engine's GPU), everything else is
+ *     host memory.  `stream` is a hipStream_t passed as void* (NULL = the engine's own stream).
+ *   - a handle is bound to one GPU and must not be used from two threads at once (the
+ *     reference's IPC object is not re-entrant either).
+ */
+#ifndef IPC_AMD_H
+#define IPC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ipc_engine ipc_engine_t;
+
+typedef enum {
+    IPC_OK = 0,
+    IPC_ERR_ARG = -1,        /* bad argument / out-of-contract graph        */
+    IPC_ERR_HIP = -2,        /* HIP runtime failure (message has the detail) */
+    IPC_ERR_STATE = -3,      /* call order (e.g. no candidates set)          */
+    IPC_ERR_LIMIT = -4       /* chain longer than the largest kernel variant */
+} ipc_status;
+
+/* The knobs the path reads: struct Config fields used by IPC::IPC
+ * (reference include/ipc/utils.hpp:22-38, src/consensus.cpp:18-32). */
+typedef struct {
+    double fast_reject_th;
+    int    fast_reject_iter_base;
+    double slow_reject_th;
+    int    slow_reject_iter_base;
+    double s_factor;
+} ipc_params_t;
+
+/* Per-cell diagnostics of the last ipc_solve_rows() (parity tests, profiling). */
+typedef struct {
+    int    i, j;             /* candidate indices (i == j: diagonal cell)   */
+    int    lo, hi;           /* vertex-id span of the sub-problem           */
+    double max_chi2;         /* max over the cell's edges of chi2           */
+    double chi2_total;       /* sum of chi2 at exit                          */
+    int    iterations;       /* dog-leg outer iterations executed            */
+    int    tries;            /* total trial steps                            */
+    int    flags;            /* bit0 Terminate, bit1 Fail                    */
+    int    pad;
+} ipc_cell_info_t;
+
+const char* ipc_last_error(void);
+
+/* Replaces IPC<EDGE,VERTEX>::IPC (reference src/consensus.cpp:9-33): takes the odometry chain
+ * (getProblemOdom + sort, :13-15), scales its information by s_factor (robustifyVoters, :21,
+ * src/consensus_utils.cpp:124-130) and propagates the open-loop guess from vertex 0
+ * (propagateGuess, :23, src/consensus_utils.cpp:99-116) -- all on the GPU `device`.
+ * dim = 2 (SE2) or 3 (SE3). odom_meas [V-1][3|7], odom_info [V-1][6|21]. */
+int ipc_create(int dim, int n_vertices, const double* odom_meas, const double* odom_info,
+               const ipc_params_t* params, int device, ipc_engine_t** out);
+
+/* Replaces IPC<EDGE,VERTEX>::~IPC (src/consensus.cpp:35-40). */
+int ipc_destroy(ipc_engine_t* h);
+
+/* The candidate list the harness feeds to agreementCheck one by one
+ * (reference src/simulation.cpp:24-26,34-47): ids [N][2] (from,to), meas [N][3|7],
+ * info [N][6|21], in FILE order; the engine applies the cmpTime processing order
+ * (src/utils.cpp:379-390) with the (max id, index) tie-break. */
+int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* meas,
+                       const double* info);
+
+/* cmpTime processing order (host copy, N ints). */
+int ipc_candidate_order(ipc_engine_t* h, int* order_out);
+
+/* Open-loop poses after propagateGuess: SE2 [V][3] (x y theta), SE3 [V][12] (R row-major, t). */
+int ipc_initial_poses(ipc_engine_t* h, double* poses_out);
+
+/* ---- consistency matrix (the batched form of
+ *      isAgreeingWithCurrentState, reference src/consensus_utils.cpp:7-22) ------------------ */
+
+/* rows per rank of the row-cyclic shard: ceil(N / world). */
+int ipc_rows_per_rank(int n, int world);
+
+/* Solve every cell (i, j >= i) whose row i satisfies i % world == rank.  d_upper is a device
+ * buffer of ipc_rows_per_rank(N, world) * ceil(N/64) uint64 words; row r holds candidate
+ * i = r*world + rank: bit j (j > i) = pair cell solved and consistent, bit i = diagonal cell
+ * consistent.  Non-overlapping pairs are not solved (their bit stays 0; see
+ * ipc_assemble_matrix). */
+int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream);
+
+/* Build the full symmetric N x N bit matrix (row-major, ceil(N/64) words per row) from the
+ * all-gathered shards d_gathered[world][rows_per_rank][words]:  C[i][j] = solved bit when the
+ * id intervals overlap with positive length (reference src/consensus.cpp:157-159), else
+ * C[i][i] & C[j][j]. */
+int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, int world,
+                        uint64_t* d_bits, void* stream);
+
+/* Greedy consistent-set maximisation over the matrix in cmpTime order (SURVEY.md 8a row P2;
+ * plays the role of computeIndependentSubgraph + accept/reject, reference
+ * src/consensus.cpp:43-75,124-171).  d_accepted: N bytes (1 = in the consensus set). */
+int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_accepted, void* stream);
+
+/* Single-GPU convenience: solve + assemble + set-max, host outputs (any may be NULL):
+ * bits_out [N][ceil(N/64)], accepted_out [N]. */
+int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_out);
+
+/* Diagnostics of the last ipc_solve_rows(): number of solved cells, and their records. */
+int ipc_cell_count(ipc_engine_t* h, int* n_cells);
+int ipc_cell_info(ipc_engine_t* h, ipc_cell_info_t* out, int capacity);
+
+/* HIP-event time (ms) spent in the cell-solver kernels of the last ipc_solve_rows(), the
+ * number of solver launches and the pose-iterations... (bench.py roofline).  Blocks until the
+ * stream has drained. */
+int ipc_solver_time_ms(ipc_engine_t* h, double* ms, int* launches);
+
+int ipc_synchronize(ipc_engine_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPC_AMD_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of include/ipc_amd.h (libipc_amd.so).
+
+This is the reference-side binding a Python caller uses; the C++ tester binds the same
+symbols directly.  The library is the product path: there is NO CPU fallback -- if the HIP
+library is missing or cannot be loaded, importing the engine raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libipc_amd.so")
+
+# every symbol include/ipc_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "ipc_last_error", "ipc_create", "ipc_destroy", "ipc_set_candidates", "ipc_candidate_order",
+    "ipc_initial_poses", "ipc_rows_per_rank", "ipc_solve_rows", "ipc_assemble_matrix", "ipc_set_max",
+    "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solver_time_ms", "ipc_synchronize",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("fast_reject_th", C.c_double), ("fast_reject_iter_base", C.c_int),
+                ("slow_reject_th", C.c_double), ("slow_reject_iter_base", C.c_int),
+                ("s_factor", C.c_double)]
+
+
+class CellInfo(C.Structure):
+    _fields_ = [("i", C.c_int), ("j", C.c_int), ("lo", C.c_int), ("hi", C.c_int),
+                ("max_chi2", C.c_double), ("chi2_total", C.c_double),
+                ("iterations", C.c_int), ("tries", C.c_int), ("flags", C.c_int), ("pad", C.c_int)]
+
+
+CELL_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("max_chi2", "<f8"),
+                       ("chi2_total", "<f8"), ("iterations", "<i4"), ("tries", "<i4"), ("flags", "<i4"),
+                       ("pad", "<i4")])
+
+_lib = None
+
+
+class IpcError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libipc_amd.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IpcError("libipc_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.ipc_last_error.restype = C.c_char_p
+    vp, ip, dp = C.c_void_p, C.c_int, C.c_double
+    lib.ipc_create.argtypes = [ip, ip, vp, vp, C.POINTER(Params), ip, C.POINTER(vp)]
+    lib.ipc_destroy.argtypes = [vp]
+    lib.ipc_set_candidates.argtypes = [vp, ip, vp, vp, vp]
+    lib.ipc_candidate_order.argtypes = [vp, vp]
+    lib.ipc_initial_poses.argtypes = [vp, vp]
+    lib.ipc_rows_per_rank.argtypes = [ip, ip]
+    lib.ipc_solve_rows.argtypes = [vp, ip, ip, vp, vp]
+    lib.ipc_assemble_matrix.argtypes = [vp, vp, ip, vp, vp]
+    lib.ipc_set_max.argtypes = [vp, vp, vp, vp]
+    lib.ipc_run.argtypes = [vp, vp, vp]
+    lib.ipc_cell_count.argtypes = [vp, C.POINTER(ip)]
+    lib.ipc_cell_info.argtypes = [vp, vp, ip]
+    lib.ipc_solver_time_ms.argtypes = [vp, C.POINTER(dp), C.POINTER(ip)]
+    lib.ipc_synchronize.argtypes = [vp]
+    assert C.sizeof(CellInfo) == CELL_DTYPE.itemsize
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IpcError("ipc_amd error %d: %s" % (rc, load().ipc_last_error().decode()))

@@ -1,0 +1,671 @@
+// libipc_amd.so -- C ABI (include/ipc_amd.h) over the gfx950 kernels.
+//
+// Device-side pipeline of one ipc_solve_rows():
+//   k_plan_count / k_plan_fill   enumerate the cells of this rank's rows, bin them by chain
+//                                length L into (threads, poses-per-thread) kernel variants
+//   se2_cells_kernel<T,M,NL>     one workgroup per cell (se2_cell.hpp)            <- hot kernel
+//   k_scatter_bits               cell results -> bit rows of the shard
+// then ipc_assemble_matrix (k_assemble) and ipc_set_max (k_set_max).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ipc_amd.h"
+#include "se2_cell.hpp"
+
+using namespace ipc;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(IPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" const char* ipc_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// kernel variants: (threads per cell, poses per thread); capacity = T*M poses
+// ------------------------------------------------------------------------------------------
+struct Variant { int T, M; };
+static const Variant kVariants[] = {
+    {64, 1}, {64, 2}, {64, 4}, {256, 2}, {256, 3}, {256, 4}, {256, 5}, {512, 4}, {1024, 4}, {1024, 8}, {1024, 16},
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kMaxBins = 16;
+struct BinCaps { int n; int cap[kMaxBins]; };
+
+__device__ __forceinline__ int bin_of(const BinCaps& bc, int L)
+{
+    int b = 0;
+    while (b < bc.n && L > bc.cap[b]) ++b;
+    return b;                                       // == bc.n => too long
+}
+
+// ------------------------------------------------------------------------------------------
+// one-off preparation kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv_sym3(const double* a, double* o)
+{
+    // a = (00 01 02 11 12 22)
+    const double c00 = a[3] * a[5] - a[4] * a[4];
+    const double c01 = a[2] * a[4] - a[1] * a[5];
+    const double c02 = a[1] * a[4] - a[2] * a[3];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a[0] * a[5] - a[2] * a[2]) * id;
+    o[4] = (a[1] * a[2] - a[0] * a[4]) * id;
+    o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+}
+
+// raw file records -> field-major SE2 records (robustifyVoters: info *= scale)
+__global__ void k_se2_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double tx = meas[3 * k], ty = meas[3 * k + 1], th = meas[3 * k + 2];
+    double s, c;
+    sincos(th, &s, &c);
+    rec[(size_t)F_TZX * stride + k] = tx;
+    rec[(size_t)F_TZY * stride + k] = ty;
+    rec[(size_t)F_CZ * stride + k] = c;
+    rec[(size_t)F_SZ * stride + k] = s;
+    rec[(size_t)F_THZ * stride + k] = th;
+    double om[6], sg[6];
+    for (int q = 0; q < 6; ++q) om[q] = info[6 * k + q] * scale;
+    inv_sym3(om, sg);
+    for (int q = 0; q < 6; ++q) {
+        rec[(size_t)(F_OM + q) * stride + k] = om[q];
+        rec[(size_t)(F_SG + q) * stride + k] = sg[q];
+    }
+}
+
+// propagateGuess (reference src/consensus_utils.cpp:99-116): v0 at origin, v[i] = v[i-1] * z[i-1]
+// (SE2::operator*: t += R t2, theta = normalize(theta + theta2)).  Sequential by nature and run
+// once per engine, so a single lane walks the chain.
+__global__ void k_se2_propagate(int V, const double* rec, int stride, double* pose0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double x = 0, y = 0, th = 0;
+    pose0[0] = x; pose0[V] = y; pose0[2 * (size_t)V] = th;
+    for (int i = 1; i < V; ++i) {
+        double s, c;
+        sincos(th, &s, &c);
+        const double tx = rec[(size_t)F_TZX * stride + i - 1], ty = rec[(size_t)F_TZY * stride + i - 1];
+        x += c * tx - s * ty;
+        y += s * tx + c * ty;
+        th = normalize_theta(th + rec[(size_t)F_THZ * stride + i - 1]);
+        pose0[i] = x; pose0[(size_t)V + i] = y; pose0[2 * (size_t)V + i] = th;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// planning: which cells does this rank solve, and with which kernel variant
+// ------------------------------------------------------------------------------------------
+// counts layout: [2][kMaxBins+1]  (0: diagonal cells, 1: pair cells; last slot = too long)
+__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world, BinCaps bc,
+                       unsigned* counters, const unsigned* offsets, int2* cells, int fill)
+{
+    const int i = blockIdx.y;
+    if (i % world != rank) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int slot = -1;
+    if (j < N && j >= i) {
+        const int loi = lo[i], hii = hi[i];
+        if (j == i) slot = bin_of(bc, hii - loi);
+        else {
+            const int loj = lo[j], hij = hi[j];
+            if (min(hii, hij) - max(loi, loj) > 0)            // reference src/consensus.cpp:157-159
+                slot = (kMaxBins + 1) + bin_of(bc, max(hii, hij) - min(loi, loj));
+        }
+    }
+    // wave-aggregated append: one atomic per (wave, slot present)
+    unsigned long long todo = __ballot(slot >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int sl = __shfl(slot, leader, 64);
+        const unsigned long long same = __ballot(slot == sl);
+        const int nsame = __popcll(same);
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&counters[sl], (unsigned)nsame);
+        base = __shfl(base, leader, 64);
+        if (slot == sl && fill) {
+            const int rnk = __popcll(same & ((1ull << lane) - 1ull));
+            cells[offsets[sl] + base + rnk] = make_int2(i, j);
+        }
+        todo &= ~same;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the hot kernel
+// ------------------------------------------------------------------------------------------
+struct CellOut {
+    double* max_chi2;
+    double* chi2_total;
+    int4* meta;               // iterations, tries, flags, L
+};
+
+template <int T, int M, int NL>
+__global__ __launch_bounds__(T) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
+                                                      SolveParams prm, CellOut out)
+{
+    __shared__ Se2Shared<T, M> sh;
+    const int cell = blockIdx.x;
+    if (cell >= ncells) return;
+    const int2 cc = cells[cell];
+    int cand[2] = {cc.x, cc.y};
+    int lo = min(P.cand_from[cc.x], P.cand_to[cc.x]), hi = max(P.cand_from[cc.x], P.cand_to[cc.x]);
+    if (NL == 2) {
+        lo = min(lo, min(P.cand_from[cc.y], P.cand_to[cc.y]));
+        hi = max(hi, max(P.cand_from[cc.y], P.cand_to[cc.y]));
+    }
+    const int L = hi - lo;
+    const int base = NL == 1 ? prm.fast_iter : prm.slow_iter;
+    const int iterations = (L + NL > 100) ? base * 5 : base;       // consensus_utils.cpp:12-13
+    CellResult r;
+    se2_solve_cell<T, M, NL>(P, lo, L, cand, iterations, sh, r);
+    if (threadIdx.x == 0) {
+        out.max_chi2[cell] = r.max_chi2;
+        out.chi2_total[cell] = r.chi2_total;
+        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, L);
+    }
+}
+
+template <int NL>
+static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,
+                             SolveParams prm, CellOut out)
+{
+#define IPC_CASE(idx, TT, MM)                                                                     \
+    case idx:                                                                                     \
+        hipLaunchKernelGGL((se2_cells_kernel<TT, MM, NL>), dim3(n), dim3(TT), 0, st, P, cells, n, prm, out); \
+        break;
+    switch (variant) {
+        IPC_CASE(0, 64, 1)
+        IPC_CASE(1, 64, 2)
+        IPC_CASE(2, 64, 4)
+        IPC_CASE(3, 256, 2)
+        IPC_CASE(4, 256, 3)
+        IPC_CASE(5, 256, 4)
+        IPC_CASE(6, 256, 5)
+        IPC_CASE(7, 512, 4)
+        IPC_CASE(8, 1024, 4)
+        IPC_CASE(9, 1024, 8)
+        IPC_CASE(10, 1024, 16)
+        default: return hipErrorInvalidValue;
+    }
+#undef IPC_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// results -> bits
+// ------------------------------------------------------------------------------------------
+__global__ void k_scatter_bits(int ncells, const int2* cells, const double* chi, double fast_th,
+                               double slow_th, int world, int words, unsigned long long* upper)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int2 cc = cells[c];
+    const double th = cc.x == cc.y ? fast_th : slow_th;
+    const bool ok = !(chi[c] > th);                 // consensus_utils.cpp:18 (NaN agrees, as there)
+    if (ok) atomicOr(&upper[(size_t)(cc.x / world) * words + (cc.y >> 6)], 1ull << (cc.y & 63));
+}
+
+__global__ void k_assemble(int N, int words, int world, int rpr, const int* lo, const int* hi,
+                           const unsigned long long* gathered, unsigned long long* bits)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (w >= words) return;
+    auto U = [&](int a, int c) -> unsigned {        // a <= c
+        const unsigned long long word = gathered[((size_t)(a % world) * rpr + a / world) * words + (c >> 6)];
+        return (unsigned)((word >> (c & 63)) & 1ull);
+    };
+    const int loi = lo[i], hii = hi[i];
+    const unsigned di = U(i, i);
+    unsigned long long out = 0;
+    for (int b = 0; b < 64; ++b) {
+        const int j = w * 64 + b;
+        if (j >= N) break;
+        unsigned bit;
+        if (j == i) bit = di;
+        else if (min(hii, hi[j]) - max(loi, lo[j]) > 0) bit = U(min(i, j), max(i, j));
+        else bit = di & U(j, j);
+        out |= (unsigned long long)bit << b;
+    }
+    bits[(size_t)i * words + w] = out;
+}
+
+// Greedy set-max: candidates in processing order, 16 per round (one wave each).
+__global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* order,
+                                                  const unsigned long long* bits, unsigned char* accepted)
+{
+    extern __shared__ unsigned long long acc[];     // [words] accepted mask
+    __shared__ int okflag[16];
+    __shared__ unsigned conf[16];
+    __shared__ int kk[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int w = tid; w < words; w += blockDim.x) acc[w] = 0ull;
+    for (int k = tid; k < N; k += blockDim.x) accepted[k] = 0;
+    __syncthreads();
+    for (int base = 0; base < N; base += 16) {
+        const int pos = base + wave;
+        const int k = pos < N ? order[pos] : -1;
+        bool ok = k >= 0;
+        if (k >= 0) {
+            const unsigned long long* row = bits + (size_t)k * words;
+            for (int w = lane; w < words; w += 64) {
+                const unsigned long long a = acc[w];
+                if ((row[w] & a) != a) ok = false;
+            }
+            ok = (__ballot(!ok) == 0ull);
+            if (!((row[k >> 6] >> (k & 63)) & 1ull)) ok = false;   // own diagonal
+        }
+        if (lane == 0) { okflag[wave] = ok ? 1 : 0; kk[wave] = k; }
+        __syncthreads();
+        if (k >= 0) {
+            // bits of this candidate against the other members of the round
+            unsigned m = 0;
+            if (lane < 16 && kk[lane] >= 0) {
+                const int o = kk[lane];
+                m = (unsigned)((bits[(size_t)k * words + (o >> 6)] >> (o & 63)) & 1ull);
+            }
+            const unsigned long long bal = __ballot(m != 0);
+            if (lane == 0) conf[wave] = (unsigned)(bal & 0xffffull);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned taken = 0;
+            for (int w = 0; w < 16; ++w) {
+                if (kk[w] < 0 || !okflag[w]) continue;
+                if ((conf[w] & taken) != taken) continue;
+                taken |= 1u << w;
+                acc[kk[w] >> 6] |= 1ull << (kk[w] & 63);
+                accepted[kk[w]] = 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------
+struct ipc_engine {
+    int dim = 2, V = 0, N = 0, device = 0;
+    ipc_params_t prm{};
+    hipStream_t own_stream = nullptr;
+    // chain
+    double* d_chain = nullptr; int estride = 0;
+    double* d_pose0 = nullptr;
+    // candidates
+    double* d_cand = nullptr; int cstride = 0;
+    int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
+    std::vector<int> order, h_lo, h_hi;
+    // plan / results of the last solve
+    unsigned* d_counters = nullptr;   // [2*(kMaxBins+1)]
+    unsigned* d_offsets = nullptr;
+    int2* d_cells = nullptr; size_t cells_cap = 0;
+    double *d_chi = nullptr, *d_chitot = nullptr; int4* d_meta = nullptr;
+    int last_cells = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false; int last_launches = 0;
+    // scratch for ipc_run
+    unsigned long long *d_upper = nullptr, *d_bits = nullptr; unsigned char* d_acc = nullptr; size_t run_cap = 0;
+};
+
+static BinCaps make_caps()
+{
+    BinCaps bc;
+    bc.n = kNumVariants;
+    for (int b = 0; b < kMaxBins; ++b) bc.cap[b] = b < kNumVariants ? kVariants[b].T * kVariants[b].M : 0;
+    return bc;
+}
+
+extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
+
+extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, const double* odom_info,
+                          const ipc_params_t* params, int device, ipc_engine_t** out)
+{
+    if (!out) return fail(IPC_ERR_ARG, "ipc_create: out is NULL");
+    *out = nullptr;
+    if (dim != 2) return fail(IPC_ERR_ARG, "ipc_create: dim=%d not supported by this build (SE2 only)", dim);
+    if (n_vertices < 2 || !odom_meas || !odom_info || !params)
+        return fail(IPC_ERR_ARG, "ipc_create: need >= 2 vertices and non-NULL arrays");
+    if (!(params->s_factor > 0)) return fail(IPC_ERR_ARG, "ipc_create: s_factor must be > 0");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(IPC_ERR_ARG, "ipc_create: device %d of %d", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    ipc_engine* h = new ipc_engine();
+    h->dim = dim; h->V = n_vertices; h->prm = *params; h->device = device;
+    const int E = n_vertices - 1;
+    h->estride = (E + 63) & ~63;
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * F_NFIELDS * h->estride));
+    HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * 3 * (size_t)n_vertices));
+    HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1)));
+    HIPCHK(hipMalloc(&h->d_offsets, sizeof(unsigned) * 2 * (kMaxBins + 1)));
+    double *d_m = nullptr, *d_i = nullptr;
+    HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * E));
+    HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * E));
+    HIPCHK(hipMemcpy(d_m, odom_meas, sizeof(double) * 3 * E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_i, odom_info, sizeof(double) * 6 * E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * F_NFIELDS * h->estride, h->own_stream));
+    hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
+                       params->s_factor, h->d_chain, h->estride);
+    hipLaunchKernelGGL(k_se2_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
+                       h->d_pose0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->own_stream));
+    HIPCHK(hipFree(d_m));
+    HIPCHK(hipFree(d_i));
+    *out = h;
+    return IPC_OK;
+}
+
+static void free_candidates(ipc_engine* h)
+{
+    hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order);
+    h->d_cand = nullptr; h->d_from = h->d_to = h->d_lo = h->d_hi = h->d_order = nullptr;
+    h->N = 0;
+}
+
+extern "C" int ipc_destroy(ipc_engine_t* h)
+{
+    if (!h) return IPC_OK;
+    hipSetDevice(h->device);
+    free_candidates(h);
+    hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets);
+    hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
+    hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return IPC_OK;
+}
+
+extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* meas, const double* info)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_set_candidates: NULL handle");
+    if (n < 0 || (n > 0 && (!ids || !meas || !info))) return fail(IPC_ERR_ARG, "ipc_set_candidates: bad arrays");
+    HIPCHK(hipSetDevice(h->device));
+    free_candidates(h);
+    h->last_cells = 0;
+    h->ev_valid = false;
+    if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
+    std::vector<int> from(n), to(n);
+    h->h_lo.resize(n); h->h_hi.resize(n);
+    const int maxL = kVariants[kNumVariants - 1].T * kVariants[kNumVariants - 1].M;
+    for (int k = 0; k < n; ++k) {
+        from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
+        if (from[k] < 0 || to[k] < 0 || from[k] >= h->V || to[k] >= h->V)
+            return fail(IPC_ERR_ARG, "candidate %d joins vertex %d-%d outside 0..%d", k, from[k], to[k], h->V - 1);
+        if (std::abs(from[k] - to[k]) < 2)
+            return fail(IPC_ERR_ARG, "candidate %d joins adjacent vertices %d-%d (an odometry edge, "
+                        "reference src/utils.cpp:184)", k, from[k], to[k]);
+        h->h_lo[k] = std::min(from[k], to[k]); h->h_hi[k] = std::max(from[k], to[k]);
+    }
+    (void)maxL;
+    // cmpTime order (src/utils.cpp:379-390) with the (max id, index) tie-break
+    h->order.resize(n);
+    std::iota(h->order.begin(), h->order.end(), 0);
+    std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
+    h->N = n;
+    h->cstride = (n + 63) & ~63;
+    HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * F_NFIELDS * h->cstride));
+    HIPCHK(hipMalloc(&h->d_from, sizeof(int) * n));
+    HIPCHK(hipMalloc(&h->d_to, sizeof(int) * n));
+    HIPCHK(hipMalloc(&h->d_lo, sizeof(int) * n));
+    HIPCHK(hipMalloc(&h->d_hi, sizeof(int) * n));
+    HIPCHK(hipMalloc(&h->d_order, sizeof(int) * n));
+    HIPCHK(hipMemcpy(h->d_from, from.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_to, to.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_lo, h->h_lo.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_hi, h->h_hi.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_order, h->order.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    double *d_m = nullptr, *d_i = nullptr;
+    HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * n));
+    HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * n));
+    HIPCHK(hipMemcpy(d_m, meas, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_i, info, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * F_NFIELDS * h->cstride, h->own_stream));
+    hipLaunchKernelGGL(k_se2_prep, dim3((n + 255) / 256), dim3(256), 0, h->own_stream, n, d_m, d_i, 1.0,
+                       h->d_cand, h->cstride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->own_stream));
+    HIPCHK(hipFree(d_m));
+    HIPCHK(hipFree(d_i));
+    return IPC_OK;
+}
+
+extern "C" int ipc_candidate_order(ipc_engine_t* h, int* order_out)
+{
+    if (!h || !order_out) return fail(IPC_ERR_ARG, "ipc_candidate_order: NULL argument");
+    std::copy(h->order.begin(), h->order.end(), order_out);
+    return IPC_OK;
+}
+
+extern "C" int ipc_initial_poses(ipc_engine_t* h, double* poses_out)
+{
+    if (!h || !poses_out) return fail(IPC_ERR_ARG, "ipc_initial_poses: NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> tmp(3 * (size_t)h->V);
+    HIPCHK(hipMemcpy(tmp.data(), h->d_pose0, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->V; ++i)
+        for (int f = 0; f < 3; ++f) poses_out[3 * (size_t)i + f] = tmp[(size_t)f * h->V + i];
+    return IPC_OK;
+}
+
+static Se2View make_view(const ipc_engine* h)
+{
+    Se2View P;
+    P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
+    P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
+    return P;
+}
+
+extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_solve_rows: NULL handle");
+    if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_solve_rows: no candidates set");
+    if (world < 1 || rank < 0 || rank >= world) return fail(IPC_ERR_ARG, "ipc_solve_rows: rank %d of %d", rank, world);
+    if (!d_upper) return fail(IPC_ERR_ARG, "ipc_solve_rows: d_upper is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
+    const BinCaps bc = make_caps();
+    constexpr int NS = 2 * (kMaxBins + 1);
+    HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
+    // pass 1: count
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS, st));
+    const dim3 pgrid((N + 255) / 256, N), pblock(256);
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
+                       h->d_offsets, (int2*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    unsigned counts[NS], offsets[NS];
+    HIPCHK(hipMemcpyAsync(counts, h->d_counters, sizeof counts, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (counts[kNumVariants] || counts[(kMaxBins + 1) + kNumVariants])
+        return fail(IPC_ERR_LIMIT, "a sub-problem spans more than %d poses (largest kernel variant)",
+                    kVariants[kNumVariants - 1].T * kVariants[kNumVariants - 1].M);
+    size_t total = 0;
+    for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
+    if (total > h->cells_cap) {
+        hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
+        h->d_cells = nullptr; h->d_chi = h->d_chitot = nullptr; h->d_meta = nullptr;
+        h->cells_cap = total + total / 8 + 1024;
+        HIPCHK(hipMalloc(&h->d_cells, sizeof(int2) * h->cells_cap));
+        HIPCHK(hipMalloc(&h->d_chi, sizeof(double) * h->cells_cap));
+        HIPCHK(hipMalloc(&h->d_chitot, sizeof(double) * h->cells_cap));
+        HIPCHK(hipMalloc(&h->d_meta, sizeof(int4) * h->cells_cap));
+    }
+    // pass 2: fill
+    HIPCHK(hipMemcpyAsync(h->d_offsets, offsets, sizeof offsets, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS, st));
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
+                       h->d_offsets, h->d_cells, 1);
+    HIPCHK(hipGetLastError());
+    // solve: longest chains first
+    const Se2View P = make_view(h);
+    const SolveParams sp{h->prm.fast_reject_iter_base, h->prm.slow_reject_iter_base};
+    int launches = 0;
+    HIPCHK(hipEventRecord(h->ev0, st));
+    for (int b = kNumVariants - 1; b >= 0; --b) {
+        for (int nl = 2; nl >= 1; --nl) {
+            const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
+            if (!counts[s]) continue;
+            CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
+            hipError_t e = nl == 1 ? launch_se2<1>(b, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
+                                   : launch_se2<2>(b, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+            if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
+            ++launches;
+        }
+    }
+    HIPCHK(hipEventRecord(h->ev1, st));
+    h->ev_valid = true;
+    h->last_launches = launches;
+    h->last_cells = (int)total;
+    if (total)
+        hipLaunchKernelGGL(k_scatter_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
+                           h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, world, words,
+                           (unsigned long long*)d_upper);
+    HIPCHK(hipGetLastError());
+    return IPC_OK;
+}
+
+extern "C" int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, int world, uint64_t* d_bits,
+                                   void* stream)
+{
+    if (!h || !d_gathered || !d_bits) return fail(IPC_ERR_ARG, "ipc_assemble_matrix: NULL argument");
+    if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_assemble_matrix: no candidates set");
+    if (world < 1) return fail(IPC_ERR_ARG, "ipc_assemble_matrix: world %d", world);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
+    hipLaunchKernelGGL(k_assemble, dim3((words + 63) / 64, N), dim3(64), 0, st, N, words, world, rpr, h->d_lo,
+                       h->d_hi, (const unsigned long long*)d_gathered, (unsigned long long*)d_bits);
+    HIPCHK(hipGetLastError());
+    return IPC_OK;
+}
+
+extern "C" int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_accepted, void* stream)
+{
+    if (!h || !d_bits || !d_accepted) return fail(IPC_ERR_ARG, "ipc_set_max: NULL argument");
+    if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_set_max: no candidates set");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const int N = h->N, words = (N + 63) / 64;
+    const size_t shmem = sizeof(unsigned long long) * words;
+    if (shmem > 60 * 1024) return fail(IPC_ERR_LIMIT, "ipc_set_max: N=%d exceeds the LDS-resident mask", N);
+    hipLaunchKernelGGL(k_set_max, dim3(1), dim3(1024), shmem, st, N, words, h->d_order,
+                       (const unsigned long long*)d_bits, d_accepted);
+    HIPCHK(hipGetLastError());
+    return IPC_OK;
+}
+
+extern "C" int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_out)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_run: NULL handle");
+    if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_run: no candidates set");
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->N, words = (N + 63) / 64;
+    const size_t need = (size_t)N * words;
+    if (need > h->run_cap) {
+        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+        h->d_upper = h->d_bits = nullptr; h->d_acc = nullptr;
+        HIPCHK(hipMalloc(&h->d_upper, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h->d_bits, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h->d_acc, (size_t)N + 64));
+        h->run_cap = need;
+    }
+    int rc = ipc_solve_rows(h, 0, 1, (uint64_t*)h->d_upper, h->own_stream);
+    if (rc) return rc;
+    rc = ipc_assemble_matrix(h, (const uint64_t*)h->d_upper, 1, (uint64_t*)h->d_bits, h->own_stream);
+    if (rc) return rc;
+    rc = ipc_set_max(h, (const uint64_t*)h->d_bits, h->d_acc, h->own_stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->own_stream));
+    if (bits_out) HIPCHK(hipMemcpy(bits_out, h->d_bits, sizeof(uint64_t) * need, hipMemcpyDeviceToHost));
+    if (accepted_out) HIPCHK(hipMemcpy(accepted_out, h->d_acc, (size_t)N, hipMemcpyDeviceToHost));
+    return IPC_OK;
+}
+
+extern "C" int ipc_cell_count(ipc_engine_t* h, int* n_cells)
+{
+    if (!h || !n_cells) return fail(IPC_ERR_ARG, "ipc_cell_count: NULL argument");
+    *n_cells = h->last_cells;
+    return IPC_OK;
+}
+
+extern "C" int ipc_cell_info(ipc_engine_t* h, ipc_cell_info_t* out, int capacity)
+{
+    if (!h || !out) return fail(IPC_ERR_ARG, "ipc_cell_info: NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int n = std::min(capacity, h->last_cells);
+    if (n <= 0) return IPC_OK;
+    std::vector<int2> cells(n);
+    std::vector<double> chi(n), tot(n);
+    std::vector<int4> meta(n);
+    HIPCHK(hipMemcpy(cells.data(), h->d_cells, sizeof(int2) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(chi.data(), h->d_chi, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tot.data(), h->d_chitot, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(meta.data(), h->d_meta, sizeof(int4) * n, hipMemcpyDeviceToHost));
+    for (int c = 0; c < n; ++c) {
+        ipc_cell_info_t& o = out[c];
+        o.i = cells[c].x; o.j = cells[c].y;
+        o.lo = std::min(h->h_lo[o.i], h->h_lo[o.j]);
+        o.hi = std::max(h->h_hi[o.i], h->h_hi[o.j]);
+        o.max_chi2 = chi[c]; o.chi2_total = tot[c];
+        o.iterations = meta[c].x; o.tries = meta[c].y; o.flags = meta[c].z; o.pad = 0;
+    }
+    return IPC_OK;
+}
+
+extern "C" int ipc_solver_time_ms(ipc_engine_t* h, double* ms, int* launches)
+{
+    if (!h || !ms) return fail(IPC_ERR_ARG, "ipc_solver_time_ms: NULL argument");
+    if (!h->ev_valid) return fail(IPC_ERR_STATE, "ipc_solver_time_ms: no solve recorded");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    *ms = t;
+    if (launches) *launches = h->last_launches;
+    return IPC_OK;
+}
+
+extern "C" int ipc_synchronize(ipc_engine_t* h)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_synchronize: NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    return IPC_OK;
+}

@@ -1,0 +1,87 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(g, **kw):
+    from ipc_amd.consensus import IPC, Config
+    cfg = Config(**kw)
+    return IPC(g, cfg, device=0), cfg
+
+
+def _oracle_matrix(O, g, cfg):
+    return O.consistency_matrix(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, g.loop_ids, g.loop_meas,
+                                g.loop_info, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                                cfg.slow_reject_th, cfg.slow_reject_iter_base)
+
+
+def _compare_cells(O, g, cfg, eng, cells, rel=1e-5):
+    poses = O.propagate(g.dim, g.odom_meas)
+    worst = 0.0
+    for c in cells:
+        solved, mx, it = O.pair_cell(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids,
+                                     g.loop_meas, g.loop_info, int(c["i"]), int(c["j"]),
+                                     cfg.fast_reject_iter_base, cfg.slow_reject_iter_base)
+        assert solved
+        th = cfg.fast_reject_th if c["i"] == c["j"] else cfg.slow_reject_th
+        assert (not (mx > th)) == (not (c["max_chi2"] > th)), (c, mx)
+        err = abs(mx - c["max_chi2"]) / max(abs(mx), 1e-12)
+        worst = max(worst, err)
+        assert err <= rel, (c, mx)
+    return worst
+
+
+def test_initial_poses_match_oracle(oracle):
+    from ipc_amd import synth
+    g = synth.small_se2()
+    eng, _ = _engine(g)
+    assert np.allclose(eng.initial_poses(), oracle.propagate(2, g.odom_meas), rtol=0, atol=1e-11)
+
+
+def test_small_matrix_and_set_bit_exact(oracle):
+    from ipc_amd import synth
+    from ipc_amd.consensus import unpack_bits
+    O = oracle
+    g = synth.inject_outliers(synth.small_se2(), 6, seed=3)
+    eng, cfg = _engine(g)
+    bits, acc = eng.run()
+    ok, mx = _oracle_matrix(O, g, cfg)
+    assert np.array_equal(unpack_bits(bits, eng.N), ok)
+    assert np.array_equal(acc, O.set_max(ok, O.candidate_order(g.loop_ids)))
+    assert np.array_equal(eng.candidate_order(), O.candidate_order(g.loop_ids))
+    cells = eng.cell_info()
+    # every solved cell: max chi2 within 1e-5 relative of the oracle
+    for c in cells:
+        ref = mx[c["i"], c["j"]]
+        assert abs(ref - c["max_chi2"]) <= 1e-5 * max(abs(ref), 1e-12), (c, ref)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_medium_graph_all_variants(oracle, seed):
+    """A 700-pose graph: exercises the multi-wave kernel variants (L up to ~700)."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import unpack_bits
+    O = oracle
+    g = synth._se2_graph(700, 24, seed=100 + seed, laps=4.0, name="medium")
+    g = synth.inject_outliers(g, 16, seed=seed)
+    eng, cfg = _engine(g)
+    bits, acc = eng.run()
+    cells = eng.cell_info()
+    assert len(cells) > 100
+    # sample cells across the whole L range, including the longest
+    order = np.argsort(cells["hi"] - cells["lo"])
+    pick = np.unique(np.concatenate([order[:10], order[-25:], order[:: max(1, len(order) // 40)]]))
+    worst = _compare_cells(O, g, cfg, eng, cells[pick])
+    assert worst <= 1e-5
+    # symmetric, and the non-overlap rule holds
+    C = unpack_bits(bits, eng.N)
+    assert np.array_equal(C, C.T)
+    lo, hi = g.loop_ids.min(1), g.loop_ids.max(1)
+    for i in range(eng.N):
+        for j in range(eng.N):
+            if i != j and min(hi[i], hi[j]) - max(lo[i], lo[j]) <= 0:
+                assert C[i, j] == (C[i, i] & C[j, j])
+    # set-max of the GPU equals the oracle's greedy on the GPU's own matrix
+    assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
