@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- candidate-pairs/s of the consistency matrix + set-max (BASELINE.json metric).
+
+A "step" is one pass of the hot path over the whole candidate set: plan + solve every cell of
+the N x N consistency matrix (row-sharded over the ranks), all-gather the bit rows (N > 1 GPU),
+assemble the symmetric matrix and run the set-max.  Inputs (odometry chain, candidates) are
+resident in HBM before the timed region starts.
+
+Workload (config.workload): BASELINE.json configs[1] = INTEL-like SE2 graph (V=1228, 256 true
+loops) + 1000 injected outliers => N=1256, 789,396 cells (i <= j).  Synthetic stand-in -- the
+INTEL file itself is not shipped with the reference and there is no network.
+
+python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector == dense MFMA rate (half the 157.3 TF FP32 rate)
+HBM_PEAK_GBS = 8000.0
+
+# per-pose operation counts of the SE2 kernel (DESIGN.md "Kernel op count")
+F_ITER = {1: 272.0, 2: 447.0}    # b, alpha, capacitance reduction, step, scans -- per outer iteration
+F_EVAL = 80.0                    # sincos + residual + chi2 -- per error evaluation
+F_TRY = 70.0                     # step candidate, linear gain, update -- per evaluated trial
+B_ODOM = 72.0                    # bytes of one odometry record (3 + 6 doubles), SURVEY.md 8d
+
+
+def build_workload(name):
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    if name == "C2":
+        g = synth.inject_outliers(synth.intel_like(), 1000, seed=1000)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=256)
+        desc = "INTEL-like SE2 synthetic (V=1228, 256 true loops) + 1000 injected outliers"
+    elif name == "C1":
+        g = synth.inject_outliers(synth.intel_like(), 100, seed=100)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=256)
+        desc = "INTEL-like SE2 synthetic (V=1228, 256 true loops) + 100 injected outliers"
+    elif name == "C3":
+        g = synth.inject_outliers(synth.mit_like(), 5000, seed=5000)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=20)
+        desc = "MIT-like SE2 synthetic (V=808, 20 true loops) + 5000 injected outliers"
+    elif name == "tiny":
+        g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)
+        desc = "tiny SE2 synthetic (V=300) + 40 outliers"
+    else:
+        raise SystemExit("unknown workload " + name)
+    return g, cfg, desc
+
+
+def cpu_baseline(g, cfg, cells, budget_s):
+    """Times the CPU oracle (1 thread) on a bounded, L-stratified sample of the same cells."""
+    from oracle import oracle as O
+    poses = O.propagate(g.dim, g.odom_meas)
+    L = (cells["hi"] - cells["lo"]).astype(np.int64)
+    order = np.argsort(L, kind="stable")
+    n_target = 4096
+    pick = order[np.linspace(0, len(order) - 1, min(n_target, len(order))).astype(np.int64)]
+    rng = np.random.default_rng(0)
+    rng.shuffle(pick)                      # any prefix of `pick` is an unbiased stratified sample
+    t0 = time.perf_counter()
+    done = 0
+    mism = 0
+    for idx in pick:
+        c = cells[idx]
+        _, mx, _ = O.pair_cell(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids, g.loop_meas,
+                               g.loop_info, int(c["i"]), int(c["j"]), cfg.fast_reject_iter_base,
+                               cfg.slow_reject_iter_base)
+        th = cfg.fast_reject_th if c["i"] == c["j"] else cfg.slow_reject_th
+        mism += int((not (mx > th)) != (not (c["max_chi2"] > th)))
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="candidate-pairs/s", cores=1, kind="port",
+                sample="%d solved cells, uniformly drawn over the chain-length order of the same workload, "
+                       "%.1f s of CPU oracle (1 thread); non-overlapping pairs are free on both sides and "
+                       "are excluded from this rate" % (done, dt),
+                decisions_differing_from_gpu=mism)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    from ipc_amd.consensus import IPC
+    from ipc_amd.dist import EngineBackend, ShardedMatrix
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    g, cfg, desc = build_workload(args.workload)
+    eng = IPC(g, cfg, device=local_rank)               # chain + candidates now resident in HBM
+    sm = ShardedMatrix(EngineBackend(eng), rank, world)
+    N = eng.N
+    n_cells_total = N * (N + 1) // 2
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sm.step()
+    barrier()
+    solver_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sm.step()
+        if rank == 0:
+            pass
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-step solver time from HIP events recorded on the launch stream (last step)
+    sms, launches = eng.solver_time_ms()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (the cell solver launches of one step) ----
+    cells = eng.cell_info()                            # this rank's solved cells
+    L = (cells["hi"] - cells["lo"]).astype(np.float64)
+    nl = np.where(cells["i"] == cells["j"], 1, 2)
+    f_iter = np.where(nl == 1, F_ITER[1], F_ITER[2])
+    flops = float((L * (cells["iterations"] * f_iter + cells["evals"] * F_EVAL
+                        + np.maximum(cells["evals"] - 1, 0) * F_TRY)).sum())
+    alg_bytes = float((L * B_ODOM + nl * B_ODOM + 1.0 / 8).sum())
+    achieved_tflops = flops / (sms * 1e-3) / 1e12
+    roofline = {"bound": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": None,
+                "kernel": "se2_cells_kernel<T,M,NL> (%d launches per step, one per chain-length bin)" % launches,
+                "kernel_ms_per_step": round(sms, 4),
+                "algorithmic_flops_per_step": flops,
+                "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
+                "note": "FP64 vector ALU is the binding roof (MI355X: FP64 VALU = dense FP64 MFMA = 78.6 TFLOP/s); "
+                        "the HBM roof is far away, see roofline_hbm"}
+    hbm_gbs = alg_bytes / (sms * 1e-3) / 1e9
+    roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                    "algorithmic_bytes_per_step": alg_bytes}
+
+    out = {
+        "metric": "candidate-pairs/s (consistency matrix + set-max)",
+        "value": n_cells_total * args.steps / dt,
+        "unit": "candidate-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s; N=%d candidates, %d cells (i<=j), %d solved on rank 0, "
+                               "s=%.0f, fast %.3f/%d, slow %.3f/%d" % (
+                                   args.workload, desc, N, n_cells_total, len(cells), cfg.s_factor,
+                                   cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th,
+                                   cfg.slow_reject_iter_base),
+                   "parallelism": "rows%%%d + all-gather" % world if world > 1 else "1 GPU"},
+        "roofline": roofline,
+        "roofline_hbm": roofline_hbm,
+    }
+    bits, acc = sm.result()
+    out["accepted"] = int(acc.sum())
+    out["solved_cells_rank0"] = int(len(cells))
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(g, cfg, cells, args.cpu_seconds)
+        gpu_solved_rate = len(cells) * 1.0 / (sms * 1e-3)
+        out["cpu_baseline"]["gpu_solved_cells_per_s"] = gpu_solved_rate
+        out["cpu_baseline"]["speedup_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ typedef struct {
     int    iterations;       /* dog-leg outer iterations executed            */
     int    tries;            /* total trial steps                            */
     int    flags;            /* bit0 Terminate, bit1 Fail                    */
-    int    pad;
+    int    evals;            /* residual evaluations actually executed        */
 } ipc_cell_info_t;
 
 const char* ipc_last_error(void);

@@ -29,12 +29,12 @@ class Params(C.Structure):
 class CellInfo(C.Structure):
     _fields_ = [("i", C.c_int), ("j", C.c_int), ("lo", C.c_int), ("hi", C.c_int),
                 ("max_chi2", C.c_double), ("chi2_total", C.c_double),
-                ("iterations", C.c_int), ("tries", C.c_int), ("flags", C.c_int), ("pad", C.c_int)]
+                ("iterations", C.c_int), ("tries", C.c_int), ("flags", C.c_int), ("evals", C.c_int)]
 
 
 CELL_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("max_chi2", "<f8"),
                        ("chi2_total", "<f8"), ("iterations", "<i4"), ("tries", "<i4"), ("flags", "<i4"),
-                       ("pad", "<i4")])
+                       ("evals", "<i4")])
 
 _lib = None
 

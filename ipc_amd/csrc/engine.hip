@@ -166,7 +166,7 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
 struct CellOut {
     double* max_chi2;
     double* chi2_total;
-    int4* meta;               // iterations, tries, flags, L
+    int4* meta;               // iterations, tries, flags, error evaluations
 };
 
 template <int T, int M, int NL>
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(T) void se2_cells_kernel(Se2View P, const int2* cel
     if (threadIdx.x == 0) {
         out.max_chi2[cell] = r.max_chi2;
         out.chi2_total[cell] = r.chi2_total;
-        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, L);
+        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, r.evals);
     }
 }
 
@@ -644,7 +644,7 @@ extern "C" int ipc_cell_info(ipc_engine_t* h, ipc_cell_info_t* out, int capacity
         o.lo = std::min(h->h_lo[o.i], h->h_lo[o.j]);
         o.hi = std::max(h->h_hi[o.i], h->h_hi[o.j]);
         o.max_chi2 = chi[c]; o.chi2_total = tot[c];
-        o.iterations = meta[c].x; o.tries = meta[c].y; o.flags = meta[c].z; o.pad = 0;
+        o.iterations = meta[c].x; o.tries = meta[c].y; o.flags = meta[c].z; o.evals = meta[c].w;
     }
     return IPC_OK;
 }

@@ -160,6 +160,7 @@ struct CellResult {
     int iterations;
     int tries;
     int flags;                // bit0: dog-leg Terminate, bit1: capacitance not PD (Fail)
+    int evals;                // error evaluations (sincos + residual passes) executed
 };
 
 template <int T, int M>
@@ -273,7 +274,9 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     };
 
     // computeActiveErrors + activeRobustChi2 at the current poses
+    int evals = 0;
     auto eval_errors = [&]() -> double {
+        ++evals;
         exchange_poses();
         double part[1] = {0.0};
 #pragma unroll
@@ -710,6 +713,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     res.iterations = it_done;
     res.tries = tries_total;
     res.flags = flags;
+    res.evals = evals;
 }
 
 }  // namespace ipc
