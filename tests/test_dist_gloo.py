@@ -1,0 +1,133 @@
+"""world_size-2 run of the row-sharded matrix path on CPU (gloo): covers the shard layout, the
+all-gather and the reassembly + set-max plumbing of ipc_amd.dist without a GPU.  The solver
+backend is a stand-in built from the CPU oracle that emits exactly the shard format
+ipc_solve_rows() documents (include/ipc_amd.h)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OracleBackend:
+    """Stand-in with the engine's shard/assemble/set-max contract, computed on CPU."""
+
+    def __init__(self, g, cfg, ok_full):
+        self.g, self.cfg = g, cfg
+        self.N = g.N
+        self.words = (g.N + 63) // 64
+        self.ok = ok_full
+        self.lo, self.hi = g.loop_ids.min(1), g.loop_ids.max(1)
+
+    def empty_words(self, n):
+        return torch.zeros(n, dtype=torch.int64)
+
+    def empty_bytes(self, n):
+        return torch.zeros(n, dtype=torch.uint8)
+
+    def _overlap(self, i, j):
+        return min(self.hi[i], self.hi[j]) - max(self.lo[i], self.lo[j]) > 0
+
+    def solve_rows(self, rank, world, upper):
+        rpr = (self.N + world - 1) // world
+        u = np.zeros((rpr, self.words), dtype=np.uint64)
+        for i in range(rank, self.N, world):
+            for j in range(i, self.N):
+                if (j == i or self._overlap(i, j)) and self.ok[i, j]:
+                    u[i // world, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+        upper.copy_(torch.from_numpy(u.view(np.int64).reshape(-1)))
+
+    def assemble(self, gathered, world, bits):
+        rpr = (self.N + world - 1) // world
+        ga = gathered.numpy().view(np.uint64).reshape(world, rpr, self.words)
+
+        def U(a, c):
+            return int((ga[a % world, a // world, c >> 6] >> np.uint64(c & 63)) & np.uint64(1))
+
+        out = np.zeros((self.N, self.words), dtype=np.uint64)
+        for i in range(self.N):
+            for j in range(self.N):
+                if i == j:
+                    b = U(i, i)
+                elif self._overlap(i, j):
+                    b = U(min(i, j), max(i, j))
+                else:
+                    b = U(i, i) & U(j, j)
+                if b:
+                    out[i, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+        bits.copy_(torch.from_numpy(out.view(np.int64).reshape(-1)))
+
+    def set_max(self, bits, accepted):
+        from ipc_amd.consensus import unpack_bits
+        from ipc_amd.graphio import candidate_order
+        C = unpack_bits(bits.numpy().view(np.uint64).reshape(self.N, self.words), self.N)
+        acc = np.zeros(self.N, dtype=np.uint8)
+        for k in candidate_order(self.g.loop_ids):
+            if C[k, k] and all(C[k, j] for j in np.nonzero(acc)[0]):
+                acc[k] = 1
+        accepted.copy_(torch.from_numpy(acc))
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ipc_amd import graphio
+    from ipc_amd.consensus import Config, unpack_bits
+    from ipc_amd.dist import ShardedMatrix
+    g = graphio.read_g2o(os.path.join(HERE, "golden", "small_se2_spoiled_n6_seed3.g2o"))
+    exp = np.load(os.path.join(HERE, "golden", "small_se2_expected.npz"))
+    cfg = Config()
+    sm = ShardedMatrix(OracleBackend(g, cfg, exp["okmat"]), rank, world)
+    sm.step()
+    bits, acc = sm.result()
+    ok = np.array_equal(unpack_bits(bits, g.N), exp["okmat"]) and np.array_equal(acc, exp["accepted"])
+    # every rank must hold the full result (the set-max runs redundantly, no second collective)
+    q.put((rank, bool(ok), int(sm.rpr)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_matrix_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res)
+    assert all(r[2] == (14 + world - 1) // world for r in res)
+
+
+def test_single_rank_path_needs_no_process_group():
+    from ipc_amd import graphio
+    from ipc_amd.consensus import Config, unpack_bits
+    from ipc_amd.dist import ShardedMatrix
+    g = graphio.read_g2o(os.path.join(HERE, "golden", "small_se2_spoiled_n6_seed3.g2o"))
+    exp = np.load(os.path.join(HERE, "golden", "small_se2_expected.npz"))
+    sm = ShardedMatrix(OracleBackend(g, Config(), exp["okmat"]), 0, 1)
+    sm.step()
+    bits, acc = sm.result()
+    assert np.array_equal(unpack_bits(bits, g.N), exp["okmat"])
+    assert np.array_equal(acc, exp["accepted"])

@@ -85,3 +85,56 @@ def test_medium_graph_all_variants(oracle, seed):
                 assert C[i, j] == (C[i, i] & C[j, j])
     # set-max of the GPU equals the oracle's greedy on the GPU's own matrix
     assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
+
+
+@pytest.mark.parametrize("name,spoiled", [
+    ("small_se2", "small_se2_spoiled_n6_seed3.g2o"),
+    ("small_se2_local", "small_se2_local_spoiled_n5_seed9.g2o"),
+    ("small_se2_group", "small_se2_group_spoiled_n3_seed5.g2o"),
+])
+def test_golden_fixtures(name, spoiled):
+    """HIP path against the committed golden vectors (reference-script inputs, oracle outputs)."""
+    import os
+    from ipc_amd import graphio
+    from ipc_amd.consensus import unpack_bits
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = graphio.read_g2o(os.path.join(gold, spoiled))
+    exp = np.load(os.path.join(gold, name + "_expected.npz"))
+    s, fth, fit, sth, sit = exp["params"]
+    eng, cfg = _engine(g, s_factor=float(s), fast_reject_th=float(fth), fast_reject_iter_base=int(fit),
+                       slow_reject_th=float(sth), slow_reject_iter_base=int(sit))
+    bits, acc = eng.run()
+    assert np.array_equal(unpack_bits(bits, eng.N), exp["okmat"])
+    assert np.array_equal(acc, exp["accepted"])
+    for c in eng.cell_info():
+        ref = exp["maxchi2"][c["i"], c["j"]]
+        assert abs(ref - c["max_chi2"]) <= 1e-5 * max(abs(ref), 1e-12)
+
+
+def test_full_size_c1_properties_and_sampled_parity(oracle):
+    """BASELINE config C1 at full size: size-independent properties + a stratified sample of
+    cells against the oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_workload
+    from ipc_amd.consensus import IPC, unpack_bits
+    O = oracle
+    g, cfg, _ = build_workload("C1")
+    eng = IPC(g, cfg, device=0)
+    bits, acc = eng.run()
+    C = unpack_bits(bits, eng.N)
+    assert np.array_equal(C, C.T)                                  # symmetry
+    bits2, acc2 = eng.run()
+    assert np.array_equal(bits, bits2) and np.array_equal(acc, acc2)   # run-to-run determinism
+    order = O.candidate_order(g.loop_ids)
+    assert np.array_equal(acc, O.set_max(C, order))                # set-max == greedy clique on the matrix
+    A = np.nonzero(acc)[0]
+    assert np.all(C[np.ix_(A, A)] == 1)                            # accepted set is a clique
+    for k in np.nonzero(acc == 0)[0]:                              # maximal w.r.t. the processing order
+        prior = [a for a in A if list(order).index(a) < list(order).index(k)]
+        assert C[k, k] == 0 or not np.all(C[k, prior] == 1)
+    cells = eng.cell_info()
+    rng = np.random.default_rng(0)
+    pick = rng.choice(len(cells), size=40, replace=False)
+    worst = _compare_cells(O, g, cfg, eng, cells[pick])
+    assert worst <= 1e-5

@@ -1,0 +1,91 @@
+"""Host logic on CPU: g2o IO, candidate split/order, outlier injector vs the reference-generated
+golden fixtures, and the oracle against its committed expected outputs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+CASES = [
+    ("small_se2", "small_se2_clean.g2o", "small_se2_spoiled_n6_seed3.g2o", dict(n=6, seed=3)),
+    ("small_se2_local", "small_se2_clean.g2o", "small_se2_local_spoiled_n5_seed9.g2o", dict(n=5, seed=9, local=True)),
+    ("small_se2_group", "small_se2_clean.g2o", "small_se2_group_spoiled_n3_seed5.g2o", dict(n=3, seed=5, group_size=2)),
+    ("small_se3", "small_se3_clean.g2o", "small_se3_spoiled_n5_seed4.g2o", dict(n=5, seed=4)),
+]
+
+
+def test_g2o_roundtrip(tmp_path):
+    from ipc_amd import graphio, synth
+    for g in (synth.small_se2(), synth.small_se3()):
+        p = str(tmp_path / "g.g2o")
+        graphio.write_g2o(p, g)
+        r = graphio.read_g2o(p)
+        assert r.dim == g.dim and r.V == g.V and r.N == g.N
+        for a, b in ((r.odom_meas, g.odom_meas), (r.odom_info, g.odom_info), (r.loop_meas, g.loop_meas),
+                     (r.loop_info, g.loop_info), (r.vertices, g.vertices)):
+            assert np.array_equal(a, b)                  # repr() round-trips doubles exactly
+        assert np.array_equal(r.loop_ids, g.loop_ids)
+
+
+def test_reader_rejects_out_of_contract_graphs(tmp_path):
+    from ipc_amd import graphio
+    p = tmp_path / "bad.g2o"
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0\nVERTEX_SE2 3 2 0 0\n")
+    with pytest.raises(ValueError):
+        graphio.read_g2o(str(p))                         # ids not 0..V-1
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0\nEDGE_SE2 1 0 1 0 0 1 0 0 1 0 1\n")
+    with pytest.raises(ValueError):
+        graphio.read_g2o(str(p))                         # reversed odometry edge
+
+
+@pytest.mark.parametrize("name,clean,spoiled,kw", CASES)
+def test_injector_reproduces_reference_script(name, clean, spoiled, kw):
+    """ipc_amd.synth.inject_outliers == the reference's scripts/generateDataset.py (golden files
+    were written by the reference script itself, see tests/golden/make_golden.py)."""
+    from ipc_amd import graphio, synth
+    g = graphio.read_g2o(os.path.join(GOLD, clean))
+    ref = graphio.read_g2o(os.path.join(GOLD, spoiled))
+    mine = synth.inject_outliers(g, kw["n"], kw["seed"], group_size=kw.get("group_size", 1),
+                                 local=kw.get("local", False))
+    assert np.array_equal(mine.loop_ids, ref.loop_ids)
+    assert np.array_equal(mine.loop_meas, ref.loop_meas)
+    assert np.array_equal(mine.loop_info, ref.loop_info)
+    assert np.array_equal(mine.odom_meas, ref.odom_meas)
+
+
+def test_3d_injector_keeps_the_wxyz_quirk():
+    from ipc_amd import graphio
+    ref = graphio.read_g2o(os.path.join(GOLD, "small_se3_spoiled_n5_seed4.g2o"))
+    out = ref.loop_meas[-5:]
+    # the script's (w x y z) lands in g2o's (qx qy qz qw) slots: |qx| ~ 1, qw small
+    assert np.all(np.abs(out[:, 3]) > 0.9) and np.all(np.abs(out[:, 6]) < 0.5)
+
+
+@pytest.mark.parametrize("name,clean,spoiled,kw", CASES)
+def test_oracle_matches_committed_expected(oracle, name, clean, spoiled, kw):
+    from ipc_amd import graphio
+    O = oracle
+    g = graphio.read_g2o(os.path.join(GOLD, spoiled))
+    exp = np.load(os.path.join(GOLD, name + "_expected.npz"))
+    s, fth, fit, sth, sit = exp["params"]
+    ok, mx = O.consistency_matrix(g.dim, g.odom_meas, g.odom_info, float(s), g.loop_ids, g.loop_meas,
+                                  g.loop_info, float(fth), int(fit), float(sth), int(sit))
+    assert np.array_equal(ok, exp["okmat"])
+    m = ~np.isnan(exp["maxchi2"])
+    assert np.array_equal(m, ~np.isnan(mx))
+    assert np.allclose(mx[m], exp["maxchi2"][m], rtol=1e-6, atol=1e-12)
+    order = O.candidate_order(g.loop_ids)
+    assert np.array_equal(order, exp["order"])
+    assert np.array_equal(O.set_max(ok, order), exp["accepted"])
+    assert np.array_equal(graphio.candidate_order(g.loop_ids), exp["order"])
+    inc = O.IncrementalIPC(g.dim, g.odom_meas, g.odom_info, float(s), float(fth), int(fit), float(sth),
+                           int(sit), g.loop_ids, g.loop_meas, g.loop_info).run()
+    assert np.array_equal(inc, exp["incremental_accepted"])
+
+
+def test_all_golden_files_are_listed():
+    spoiled = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "*_spoiled_*.g2o")))
+    assert spoiled == sorted(c[2] for c in CASES)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd SQLite result (kernel trace) into a small text/CSV table.
+
+usage: python tools/rocpd_summary.py gpurun_out/prof_r1/c2_results.db > profiles/r1_c2_kernel_stats.csv
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+        "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+        "max(workgroup_x), sum(grid_x/workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,pct,arch_vgpr,accum_vgpr,sgpr,lds_bytes,scratch_bytes,wg_size,workgroups")
+    for r in rows:
+        print('"%s",%d,%d,%.0f,%d,%d,%.2f,%d,%d,%d,%d,%d,%d,%d' % (
+            r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / total, r[6], r[7], r[8], r[9], r[10], r[11], r[12]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
