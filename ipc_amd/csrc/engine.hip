@@ -48,9 +48,9 @@ extern "C" const char* ipc_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------
 // kernel variants: (threads per cell, poses per thread); capacity = T*M poses
 // ------------------------------------------------------------------------------------------
-struct Variant { int T, M; };
+struct Variant { int W, M; };                   // waves per cell, poses per lane
 static const Variant kVariants[] = {
-    {64, 1}, {64, 2}, {64, 4}, {256, 2}, {256, 3}, {256, 4}, {256, 5}, {512, 4}, {1024, 4}, {1024, 8}, {1024, 16},
+    {1, 1}, {2, 1}, {4, 1}, {6, 1}, {8, 1}, {12, 1}, {16, 1}, {12, 2}, {16, 2}, {16, 4}, {16, 8}, {16, 16},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kMaxBins = 16;
@@ -169,11 +169,11 @@ struct CellOut {
     int4* meta;               // iterations, tries, flags, error evaluations
 };
 
-template <int T, int M, int NL>
-__global__ __launch_bounds__(T) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
-                                                      SolveParams prm, CellOut out)
+template <int W, int M, int NL>
+__global__ __launch_bounds__(64 * W) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
+                                                           SolveParams prm, CellOut out)
 {
-    __shared__ Se2Shared<T, M> sh;
+    __shared__ Se2Shared<W, M, NL> sh;
     const int cell = blockIdx.x;
     if (cell >= ncells) return;
     const int2 cc = cells[cell];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(T) void se2_cells_kernel(Se2View P, const int2* cel
     const int base = NL == 1 ? prm.fast_iter : prm.slow_iter;
     const int iterations = (L + NL > 100) ? base * 5 : base;       // consensus_utils.cpp:12-13
     CellResult r;
-    se2_solve_cell<T, M, NL>(P, lo, L, cand, iterations, sh, r);
+    se2_solve_cell<W, M, NL>(P, lo, L, cand, iterations, sh, r);
     if (threadIdx.x == 0) {
         out.max_chi2[cell] = r.max_chi2;
         out.chi2_total[cell] = r.chi2_total;
@@ -199,22 +199,23 @@ template <int NL>
 static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,
                              SolveParams prm, CellOut out)
 {
-#define IPC_CASE(idx, TT, MM)                                                                     \
+#define IPC_CASE(idx, WW, MM)                                                                     \
     case idx:                                                                                     \
-        hipLaunchKernelGGL((se2_cells_kernel<TT, MM, NL>), dim3(n), dim3(TT), 0, st, P, cells, n, prm, out); \
+        hipLaunchKernelGGL((se2_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
         break;
     switch (variant) {
-        IPC_CASE(0, 64, 1)
-        IPC_CASE(1, 64, 2)
-        IPC_CASE(2, 64, 4)
-        IPC_CASE(3, 256, 2)
-        IPC_CASE(4, 256, 3)
-        IPC_CASE(5, 256, 4)
-        IPC_CASE(6, 256, 5)
-        IPC_CASE(7, 512, 4)
-        IPC_CASE(8, 1024, 4)
-        IPC_CASE(9, 1024, 8)
-        IPC_CASE(10, 1024, 16)
+        IPC_CASE(0, 1, 1)
+        IPC_CASE(1, 2, 1)
+        IPC_CASE(2, 4, 1)
+        IPC_CASE(3, 6, 1)
+        IPC_CASE(4, 8, 1)
+        IPC_CASE(5, 12, 1)
+        IPC_CASE(6, 16, 1)
+        IPC_CASE(7, 12, 2)
+        IPC_CASE(8, 16, 2)
+        IPC_CASE(9, 16, 4)
+        IPC_CASE(10, 16, 8)
+        IPC_CASE(11, 16, 16)
         default: return hipErrorInvalidValue;
     }
 #undef IPC_CASE
@@ -341,7 +342,7 @@ static BinCaps make_caps()
 {
     BinCaps bc;
     bc.n = kNumVariants;
-    for (int b = 0; b < kMaxBins; ++b) bc.cap[b] = b < kNumVariants ? kVariants[b].T * kVariants[b].M : 0;
+    for (int b = 0; b < kMaxBins; ++b) bc.cap[b] = b < kNumVariants ? 64 * kVariants[b].W * kVariants[b].M : 0;
     return bc;
 }
 
@@ -422,7 +423,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
-    const int maxL = kVariants[kNumVariants - 1].T * kVariants[kNumVariants - 1].M;
+    const int maxL = 64 * kVariants[kNumVariants - 1].W * kVariants[kNumVariants - 1].M;
     for (int k = 0; k < n; ++k) {
         from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
         if (from[k] < 0 || to[k] < 0 || from[k] >= h->V || to[k] >= h->V)
@@ -514,7 +515,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipStreamSynchronize(st));
     if (counts[kNumVariants] || counts[(kMaxBins + 1) + kNumVariants])
         return fail(IPC_ERR_LIMIT, "a sub-problem spans more than %d poses (largest kernel variant)",
-                    kVariants[kNumVariants - 1].T * kVariants[kNumVariants - 1].M);
+                    64 * kVariants[kNumVariants - 1].W * kVariants[kNumVariants - 1].M);
     size_t total = 0;
     for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
     if (total > h->cells_cap) {

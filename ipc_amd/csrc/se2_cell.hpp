@@ -1,0 +1,856 @@
+// SE(2) consistency cell solver -- one workgroup per cell, hand-written for gfx950 (wave64).
+//
+// A cell is the reference's isAgreeingWithCurrentState (reference src/consensus_utils.cpp:7-22)
+// applied to: the odometry chain lo..hi (gauge = pose lo fixed, reference
+// src/consensus_utils.cpp:29-43), the open-loop initial guess (src/consensus_utils.cpp:99-116),
+// odometry information pre-scaled by s (src/consensus_utils.cpp:124-130) and ONE (diagonal cell)
+// or TWO (pair cell) loop-closure edges; the optimiser is g2o's dog-leg
+// ("dl_var", src/utils.cpp:105) run for iter_base*(5 if #edges>100) iterations, then
+// max_e chi2_e is compared with the threshold by the caller.
+//
+// MI355X-first formulation (this is not how g2o does the linear algebra):
+//   * Pose j (1..L) of the chain lives in the registers of ONE lane: wave w owns poses
+//     [w*64*M+1, (w+1)*64*M], slot s / lane l holds pose w*64*M + s*64 + l + 1.  Consecutive
+//     lanes hold consecutive poses, so every load of the shared odometry chain is a fully
+//     coalesced 512-byte wave access and the chain neighbour (j-1 / j+1) is one DPP
+//     wave_shr/wave_shl away; only the 2*W wave-boundary values cross LDS.
+//   * The Gauss-Newton step H h = b is NOT obtained by factoring the (block tridiagonal +
+//     arrow) H.  With u = Jc h (Jc = square block-bidiagonal Jacobian of the odometry chain)
+//     the normal equations become  (Om_c + G^T Om_l G) u = Jc^-T b  with G = Jl Jc^-1, and for
+//     SE(2) Jc^-1 has the closed form "propagate a perturbation down the chain":
+//         h_theta(i) = sum_{j<=i} rho_theta(j),
+//         h_t(i)     = sum_{j<=i} [ rho_t(j) + J (t_j - t_{j-1}) h_theta(j-1) ],   J=[[0,-1],[1,0]]
+//     so G is element-wise, the capacitance matrix S = Cov_l + sum_j G_j Cov_j G_j^T is a
+//     3x3 / 6x6 reduction, and h follows from prefix sums (DPP wave scans + one LDS hop).
+//   * Dog-leg bookkeeping follows g2o exactly (delta, rho, <=100 trials, Terminate).  A trial
+//     is evaluated WITHOUT committing (trial poses/errors sit beside the current ones), so a
+//     rejected trial costs no restore pass.  Two shortcuts are taken that are bit-exact w.r.t.
+//     the un-shortcut loop:
+//       - a rejected Gauss-Newton trial repeats identically while ||h_gn|| < delta, so those
+//         repeats only halve delta and count trials;
+//       - a steepest-descent trial whose update leaves every pose bit-identical has
+//         newChi == currentChi (rho = 0, rejected) and so have all later, halved ones: the
+//         trial counter is fast-forwarded to Terminate.
+//   * Every phase is: element-wise work -> one __syncthreads -> read what the other waves
+//     published.  All LDS scratch is double buffered on the phase parity, which makes one
+//     barrier per phase sufficient.
+#pragma once
+#include "block_prims.hpp"
+
+namespace ipc {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// chain / candidate record fields (structure of arrays, field-major)
+enum Se2Field { F_TZX = 0, F_TZY, F_CZ, F_SZ, F_THZ, F_OM = 5, F_SG = 11, F_NFIELDS = 17 };
+
+struct Se2View {
+    const double* chain;      // [F_NFIELDS][estride], index = edge k (joins pose k -> k+1)
+    int estride;
+    const double* pose0;      // [3][V] open-loop poses x, y, theta
+    int V;
+    const double* cand;       // [F_NFIELDS][cstride] per loop candidate
+    int cstride;
+    const int* cand_from;     // candidate "from" / "to" vertex ids
+    const int* cand_to;
+};
+
+struct SolveParams {
+    int fast_iter, slow_iter;
+};
+
+__device__ __forceinline__ double normalize_theta(double theta)
+{
+    if (theta >= -kPi && theta < kPi) return theta;
+    double multiplier = floor(theta / (2 * kPi));
+    theta = theta - multiplier * 2 * kPi;
+    if (theta >= kPi) theta -= 2 * kPi;
+    if (theta < -kPi) theta += 2 * kPi;
+    return theta;
+}
+
+struct Sym3 {                 // symmetric 3x3: 00 01 02 11 12 22
+    double a00, a01, a02, a11, a12, a22;
+    __device__ __forceinline__ void mul(double x, double y, double z, double& ox, double& oy, double& oz) const
+    {
+        ox = a00 * x + a01 * y + a02 * z;
+        oy = a01 * x + a11 * y + a12 * z;
+        oz = a02 * x + a12 * y + a22 * z;
+    }
+    __device__ __forceinline__ double quad(double x, double y, double z) const
+    {
+        double ox, oy, oz;
+        mul(x, y, z, ox, oy, oz);
+        return x * ox + y * oy + z * oz;
+    }
+};
+
+__device__ __forceinline__ Sym3 load_sym3(const double* base, int stride, int field0, int idx)
+{
+    Sym3 s;
+    s.a00 = base[(size_t)(field0 + 0) * stride + idx];
+    s.a01 = base[(size_t)(field0 + 1) * stride + idx];
+    s.a02 = base[(size_t)(field0 + 2) * stride + idx];
+    s.a11 = base[(size_t)(field0 + 3) * stride + idx];
+    s.a12 = base[(size_t)(field0 + 4) * stride + idx];
+    s.a22 = base[(size_t)(field0 + 5) * stride + idx];
+    return s;
+}
+
+struct Pose2 { double x, y, th, c, s; };
+
+// error of an SE2 edge a -> b with measurement (tz, cz, sz, thz)
+__device__ __forceinline__ void se2_error(const Pose2& a, const Pose2& b, double tzx, double tzy,
+                                          double cz, double sz, double thz, double& ex, double& ey,
+                                          double& eth)
+{
+    const double dx = b.x - a.x, dy = b.y - a.y;
+    const double rx = a.c * dx + a.s * dy;
+    const double ry = -a.s * dx + a.c * dy;
+    const double lx = rx - tzx, ly = ry - tzy;
+    ex = cz * lx + sz * ly;
+    ey = -sz * lx + cz * ly;
+    eth = normalize_theta(normalize_theta(b.th - a.th) - thz);
+}
+
+// w = J_edge applied to the pose perturbations (va at pose a, vb at pose b) of an edge a -> b
+// with current poses a, b and measurement rotation (cz, sz):
+//   w_t = Rz^T [ R_a^T (vb_t - va_t) - J r va_theta ],  r = R_a^T (t_b - t_a);  w_th = vb_th - va_th
+__device__ __forceinline__ void se2_apply_J(const Pose2& a, const Pose2& b, double cz, double sz,
+                                            double vax, double vay, double vath, double vbx, double vby,
+                                            double vbth, double& wx, double& wy, double& wth)
+{
+    const double dx = b.x - a.x, dy = b.y - a.y;
+    const double rx = a.c * dx + a.s * dy, ry = -a.s * dx + a.c * dy;
+    const double ddx = vbx - vax, ddy = vby - vay;
+    const double lx = a.c * ddx + a.s * ddy + ry * vath;
+    const double ly = -a.s * ddx + a.c * ddy - rx * vath;
+    wx = cz * lx + sz * ly;
+    wy = -sz * lx + cz * ly;
+    wth = vbth - vath;
+}
+
+// SPD solve by Cholesky (n = 3 or 6), full row-major, overwritten.  One reciprocal per pivot.
+template <int N>
+__device__ __forceinline__ bool chol_solve(double (&A)[N][N], double (&b)[N])
+{
+    bool ok = true;
+    double inv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum -= A[i][k] * A[j][k];
+            if (j < i) A[i][j] = sum * inv[j];
+            else {
+                if (!(sum > 0)) ok = false;
+                A[i][i] = sqrt(sum);
+                inv[i] = 1.0 / A[i][i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sum = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= A[i][k] * b[k];
+        b[i] = sum * inv[i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double sum = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) sum -= A[k][i] * b[k];
+        b[i] = sum * inv[i];
+    }
+    return ok;
+}
+
+struct CellResult {
+    double max_chi2;
+    double chi2_total;
+    int iterations;
+    int tries;
+    int flags;                // bit0: dog-leg Terminate, bit1: capacitance not PD (Fail)
+    int evals;                // trial evaluations (sincos + residual passes) executed
+};
+
+// ---- lane-neighbour moves (DPP, full rate; no LDS) ----
+// value of lane-1; lane 0 receives `carry`
+__device__ __forceinline__ double lane_prev(double v, double carry)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(carry), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// value of lane+1; lane 63 receives `carry`
+__device__ __forceinline__ double lane_next(double v, double carry)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(carry), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// loop-closure edge: constants and per-state values, all in LDS (uniform data)
+struct LoopConst {
+    int f, t, lo, hi;         // local pose indices 0..L; lo/hi = min/max(f,t)
+    double sigma;             // +1 if t > f else -1
+    double tzx, tzy, cz, sz, thz;
+    double om[6], sg[6];
+};
+struct LoopState {
+    double pf[5], pt[5];      // end-point poses (x y th c s)
+    double e[3];              // error
+    double g[3];              // world-frame force (R_f Rz q_t, q_theta), q = Om e
+    double chi;
+};
+
+template <int W, int NL>
+struct Se2Scratch {           // per-phase hand-off, double buffered
+    double red[W][32];        // per-wave partial sums
+    double hi_pose[W][5];     // pose held by lane 63 / last slot of each wave
+    double hi_vec[W][3];      // vector held by lane 63 / last slot
+    double lo_vec[W][3];      // vector held by lane 0 / slot 0
+    double lvec[NL][2][3];    // vectors at the loop end points (from, to)
+    double scan[W][5];        // per-wave scan totals
+};
+
+template <int W, int M, int NL>
+struct Se2Shared {
+    Se2Scratch<W, NL> scr[2];
+    LoopConst lc[NL];
+    LoopState ls[2][NL];      // [buffer][loop]; `cur` selects the committed one
+};
+
+template <int W, int M, int NL>
+__device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
+                               Se2Shared<W, M, NL>& sh, CellResult& res)
+{
+    constexpr int NS = NL * 3;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jbase = 1 + wave * 64 * M + lane;      // pose index of slot 0
+
+    // ---------------- loop constants -> LDS ----------------
+    if (tid < NL) {
+        const int l = tid, c = cand[l];
+        LoopConst& q = sh.lc[l];
+        q.f = P.cand_from[c] - lo_abs;
+        q.t = P.cand_to[c] - lo_abs;
+        q.lo = min(q.f, q.t);
+        q.hi = max(q.f, q.t);
+        q.sigma = q.t > q.f ? 1.0 : -1.0;
+        q.tzx = P.cand[(size_t)F_TZX * P.cstride + c];
+        q.tzy = P.cand[(size_t)F_TZY * P.cstride + c];
+        q.cz = P.cand[(size_t)F_CZ * P.cstride + c];
+        q.sz = P.cand[(size_t)F_SZ * P.cstride + c];
+        q.thz = P.cand[(size_t)F_THZ * P.cstride + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            q.om[k] = P.cand[(size_t)(F_OM + k) * P.cstride + c];
+            q.sg[k] = P.cand[(size_t)(F_SG + k) * P.cstride + c];
+        }
+    }
+
+    // ---------------- per-lane state ----------------
+    Pose2 X[M];                                      // committed poses
+    Pose2 Xn[M];                                     // trial poses
+    double ex[M], ey[M], eth[M];                     // committed odometry errors of edge j (j-1 -> j)
+    double enx[M], eny[M], enth[M];                  // trial errors
+    double bx[M], by[M], bth[M];                     // b = -J^T Om e
+    double hx[M], hy[M], hth[M];                     // Gauss-Newton step
+    bool valid[M];
+    int ek[M];                                       // absolute edge index of the slot
+    Pose2 gauge;
+    gauge.x = P.pose0[lo_abs];
+    gauge.y = P.pose0[(size_t)P.V + lo_abs];
+    gauge.th = P.pose0[(size_t)2 * P.V + lo_abs];
+    sincos(gauge.th, &gauge.s, &gauge.c);
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        const int j = jbase + s * 64;
+        valid[s] = j <= L;
+        ek[s] = valid[s] ? lo_abs + j - 1 : lo_abs;
+        const int ja = valid[s] ? lo_abs + j : lo_abs;
+        Xn[s].x = P.pose0[ja];
+        Xn[s].y = P.pose0[(size_t)P.V + ja];
+        Xn[s].th = P.pose0[(size_t)2 * P.V + ja];
+        sincos(Xn[s].th, &Xn[s].s, &Xn[s].c);
+        X[s] = Xn[s];
+        hx[s] = hy[s] = hth[s] = 0.0;
+        bx[s] = by[s] = bth[s] = 0.0;
+        ex[s] = ey[s] = eth[s] = 0.0;
+        enx[s] = eny[s] = enth[s] = 0.0;
+    }
+    __syncthreads();                                 // sh.lc visible
+    int lf[NL], lt[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { lf[l] = sh.lc[l].f; lt[l] = sh.lc[l].t; }
+    // gauge end points never change: write them into both state buffers once
+    if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int bsel = 0; bsel < 2; ++bsel) {
+                double* pf = sh.ls[bsel][l].pf;
+                double* pt = sh.ls[bsel][l].pt;
+                if (lf[l] == 0) { pf[0] = gauge.x; pf[1] = gauge.y; pf[2] = gauge.th; pf[3] = gauge.c; pf[4] = gauge.s; }
+                if (lt[l] == 0) { pt[0] = gauge.x; pt[1] = gauge.y; pt[2] = gauge.th; pt[3] = gauge.c; pt[4] = gauge.s; }
+            }
+    }
+
+    auto ldc = [&](int field, int s) { return P.chain[(size_t)field * P.estride + ek[s]]; };
+
+    int phase = 0;                                   // scratch parity
+    int cur = 0;                                     // committed loop-state buffer
+
+    // pose of chain neighbour j-1 for every slot, from poses Y (DPP + wave-boundary value `edge`)
+    auto prev_pose = [&](const Pose2 (&Y)[M], const Pose2& edge, Pose2 (&A)[M]) {
+        Pose2 carry = edge;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            A[s].x = lane_prev(Y[s].x, carry.x);
+            A[s].y = lane_prev(Y[s].y, carry.y);
+            A[s].th = lane_prev(Y[s].th, carry.th);
+            A[s].c = lane_prev(Y[s].c, carry.c);
+            A[s].s = lane_prev(Y[s].s, carry.s);
+            carry.x = read_lane(Y[s].x, 63); carry.y = read_lane(Y[s].y, 63); carry.th = read_lane(Y[s].th, 63);
+            carry.c = read_lane(Y[s].c, 63); carry.s = read_lane(Y[s].s, 63);
+        }
+    };
+    auto prev_vec = [&](const double (&vx)[M], const double (&vy)[M], const double (&vth)[M], double e0,
+                        double e1, double e2, double (&ax)[M], double (&ay)[M], double (&ath)[M]) {
+        double c0 = e0, c1 = e1, c2 = e2;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            ax[s] = lane_prev(vx[s], c0); ay[s] = lane_prev(vy[s], c1); ath[s] = lane_prev(vth[s], c2);
+            c0 = read_lane(vx[s], 63); c1 = read_lane(vy[s], 63); c2 = read_lane(vth[s], 63);
+        }
+    };
+    // publish the wave's last pose (lane 63, slot M-1) and the loop end points of poses Y
+    auto publish_poses = [&](const Pose2 (&Y)[M], Se2Scratch<W, NL>& S, int lsbuf) {
+        if (lane == 63) {
+            S.hi_pose[wave][0] = Y[M - 1].x; S.hi_pose[wave][1] = Y[M - 1].y; S.hi_pose[wave][2] = Y[M - 1].th;
+            S.hi_pose[wave][3] = Y[M - 1].c; S.hi_pose[wave][4] = Y[M - 1].s;
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const int j = jbase + s * 64;
+                if (j == lf[l]) {
+                    double* q = sh.ls[lsbuf][l].pf;
+                    q[0] = Y[s].x; q[1] = Y[s].y; q[2] = Y[s].th; q[3] = Y[s].c; q[4] = Y[s].s;
+                }
+                if (j == lt[l]) {
+                    double* q = sh.ls[lsbuf][l].pt;
+                    q[0] = Y[s].x; q[1] = Y[s].y; q[2] = Y[s].th; q[3] = Y[s].c; q[4] = Y[s].s;
+                }
+            }
+    };
+    auto publish_vec = [&](const double (&vx)[M], const double (&vy)[M], const double (&vth)[M],
+                           Se2Scratch<W, NL>& S) {
+        if (lane == 63) { S.hi_vec[wave][0] = vx[M - 1]; S.hi_vec[wave][1] = vy[M - 1]; S.hi_vec[wave][2] = vth[M - 1]; }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (tid == 0) {
+                if (lf[l] == 0) { S.lvec[l][0][0] = 0.0; S.lvec[l][0][1] = 0.0; S.lvec[l][0][2] = 0.0; }
+                if (lt[l] == 0) { S.lvec[l][1][0] = 0.0; S.lvec[l][1][1] = 0.0; S.lvec[l][1][2] = 0.0; }
+            }
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const int j = jbase + s * 64;
+                if (j == lf[l]) { S.lvec[l][0][0] = vx[s]; S.lvec[l][0][1] = vy[s]; S.lvec[l][0][2] = vth[s]; }
+                if (j == lt[l]) { S.lvec[l][1][0] = vx[s]; S.lvec[l][1][1] = vy[s]; S.lvec[l][1][2] = vth[s]; }
+            }
+        }
+    };
+    auto edge_pose_of = [&](const Se2Scratch<W, NL>& S) -> Pose2 {
+        if (wave == 0) return gauge;
+        Pose2 p;
+        p.x = S.hi_pose[wave - 1][0]; p.y = S.hi_pose[wave - 1][1]; p.th = S.hi_pose[wave - 1][2];
+        p.c = S.hi_pose[wave - 1][3]; p.s = S.hi_pose[wave - 1][4];
+        return p;
+    };
+    // workgroup sum of K partials: DPP wave sum, lane 0 -> LDS, ONE barrier, all read.
+    // The barrier also orders everything published into the scratch / loop-state buffers before.
+    auto reduce = [&](auto& part, Se2Scratch<W, NL>& S) {
+        constexpr int K = sizeof(part) / sizeof(double);
+#pragma unroll
+        for (int k = 0; k < K; ++k) part[k] = wave_sum(part[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) S.red[wave][k] = part[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double acc = S.red[0][k];
+#pragma unroll
+            for (int w = 1; w < W; ++w) acc += S.red[w][k];
+            part[k] = acc;
+        }
+    };
+
+    // loop l: error / force / chi2 from its end-point poses in state buffer `bsel` (one lane)
+    auto loop_eval = [&](int l, int bsel) -> double {
+        const LoopConst& q = sh.lc[l];
+        LoopState& st = sh.ls[bsel][l];
+        Pose2 a{st.pf[0], st.pf[1], st.pf[2], st.pf[3], st.pf[4]};
+        Pose2 b{st.pt[0], st.pt[1], st.pt[2], st.pt[3], st.pt[4]};
+        double e0, e1, e2;
+        se2_error(a, b, q.tzx, q.tzy, q.cz, q.sz, q.thz, e0, e1, e2);
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        double q0, q1, q2;
+        om.mul(e0, e1, e2, q0, q1, q2);
+        const double chi = e0 * q0 + e1 * q1 + e2 * q2;
+        const double cP = a.c * q.cz - a.s * q.sz, sP = a.s * q.cz + a.c * q.sz;
+        st.e[0] = e0; st.e[1] = e1; st.e[2] = e2;
+        st.g[0] = cP * q0 - sP * q1; st.g[1] = sP * q0 + cP * q1; st.g[2] = q2;
+        st.chi = chi;
+        return chi;
+    };
+    // loop l: w^T Om w with w = J_l applied to the end-point vectors in S.lvec (one lane)
+    auto loop_quad = [&](int l, const Se2Scratch<W, NL>& S) -> double {
+        const LoopConst& q = sh.lc[l];
+        const LoopState& st = sh.ls[cur][l];
+        Pose2 a{st.pf[0], st.pf[1], st.pf[2], st.pf[3], st.pf[4]};
+        Pose2 b{st.pt[0], st.pt[1], st.pt[2], st.pt[3], st.pt[4]};
+        double wx, wy, wth;
+        se2_apply_J(a, b, q.cz, q.sz, S.lvec[l][0][0], S.lvec[l][0][1], S.lvec[l][0][2], S.lvec[l][1][0],
+                    S.lvec[l][1][1], S.lvec[l][1][2], wx, wy, wth);
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        return om.quad(wx, wy, wth);
+    };
+
+    // ---------------- initial errors (consensus_utils.cpp:11) ----------------
+    int evals = 0;
+    double currentChi;
+    {
+        Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+        publish_poses(X, S, cur);
+        __syncthreads();
+        Pose2 A0[M];
+        prev_pose(X, edge_pose_of(S), A0);
+        double part[1] = {0.0};
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            if (!valid[s]) continue;
+            se2_error(A0[s], X[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s),
+                      ex[s], ey[s], eth[s]);
+            part[0] += load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(ex[s], ey[s], eth[s]);
+        }
+        if (tid < NL) part[0] += loop_eval(tid, cur);
+        ++phase;
+        reduce(part, sh.scr[phase & 1]);
+        ++phase;
+        currentChi = part[0];
+        ++evals;
+    }
+
+    // ---------------- dog-leg (g2o OptimizationAlgorithmDogleg::solve) ----------------
+    double delta = 1e4;
+    const int maxTrials = 100;
+    int it_done = 0, tries_total = 0, flags = 0;
+
+    for (int it = 0; it < iterations; ++it) {
+        // committed poses X, errors e and loop state ls[cur] are consistent here
+        Pose2 A[M];                                  // committed pose j-1 per slot
+        double cP[M], sP[M];                         // P_j = R_{j-1} Rz_j
+        // ---- phase I1: forces g, hand-back m; b ----
+        {
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            publish_poses(X, S, cur);
+            __syncthreads();
+            prev_pose(X, edge_pose_of(S), A);
+            ++phase;
+            double gx[M], gy[M], gth[M], mx[M], my[M], mth[M];
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                gx[s] = gy[s] = gth[s] = mx[s] = my[s] = mth[s] = 0.0;
+                cP[s] = 1.0; sP[s] = 0.0;
+                if (!valid[s]) continue;
+                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                cP[s] = A[s].c * cz - A[s].s * sz;
+                sP[s] = A[s].s * cz + A[s].c * sz;
+                double qx, qy, qth;
+                load_sym3(P.chain, P.estride, F_OM, ek[s]).mul(ex[s], ey[s], eth[s], qx, qy, qth);
+                gx[s] = cP[s] * qx - sP[s] * qy;
+                gy[s] = sP[s] * qx + cP[s] * qy;
+                gth[s] = qth;
+                const double dx = X[s].x - A[s].x, dy = X[s].y - A[s].y;
+                mx[s] = gx[s]; my[s] = gy[s];
+                mth[s] = gth[s] + (-dy * gx[s] + dx * gy[s]);
+            }
+            Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
+            if (lane == 0) { S2.lo_vec[wave][0] = mx[0]; S2.lo_vec[wave][1] = my[0]; S2.lo_vec[wave][2] = mth[0]; }
+            __syncthreads();
+            // m of pose j+1: next lane / next slot's lane 0 / next wave's lane 0
+            double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+            if (wave + 1 < W) { n0 = S2.lo_vec[wave + 1][0]; n1 = S2.lo_vec[wave + 1][1]; n2 = S2.lo_vec[wave + 1][2]; }
+            ++phase;
+#pragma unroll
+            for (int s = M - 1; s >= 0; --s) {
+                const double ux = lane_next(mx[s], n0), uy = lane_next(my[s], n1), uth = lane_next(mth[s], n2);
+                n0 = read_lane(mx[s], 0); n1 = read_lane(my[s], 0); n2 = read_lane(mth[s], 0);
+                // invalid slots hold m = 0, so poses past the end contribute nothing
+                bx[s] = ux - gx[s]; by[s] = uy - gy[s]; bth[s] = uth - gth[s];
+                if (!valid[s]) { bx[s] = by[s] = bth[s] = 0.0; }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const LoopState& st = sh.ls[cur][l];
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    const int j = jbase + s * 64;
+                    if (j == lt[l]) { bx[s] -= st.g[0]; by[s] -= st.g[1]; bth[s] -= st.g[2]; }
+                    if (j == lf[l]) {
+                        const double dx = st.pt[0] - st.pf[0], dy = st.pt[1] - st.pf[1];
+                        bx[s] += st.g[0]; by[s] += st.g[1];
+                        bth[s] += st.g[2] + (-dy * st.g[0] + dx * st.g[1]);
+                    }
+                }
+            }
+        }
+        // ---- phase I2: b^T b, b^T H b, capacitance partials ----
+        double bb, bHb, alpha, hsdNorm, hgnNorm;
+        double Gc[M][NL][5];                          // per slot/loop: cR, sR, kx, ky, sign (0 = off)
+        double S6[NS][NS], mu[NS];
+        {
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            publish_vec(bx, by, bth, S);
+            __syncthreads();
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            if (wave > 0) { e0 = S.hi_vec[wave - 1][0]; e1 = S.hi_vec[wave - 1][1]; e2 = S.hi_vec[wave - 1][2]; }
+            double pbx[M], pby[M], pbth[M];
+            prev_vec(bx, by, bth, e0, e1, e2, pbx, pby, pbth);
+            constexpr int KR = 2 + NS + NS * (NS + 1) / 2;
+            double part[KR];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) part[k] = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) { Gc[s][l][0] = Gc[s][l][1] = Gc[s][l][2] = Gc[s][l][3] = Gc[s][l][4] = 0.0; }
+                if (!valid[s]) continue;
+                part[0] += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
+                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                double wx, wy, wth;
+                se2_apply_J(A[s], X[s], cz, sz, pbx[s], pby[s], pbth[s], bx[s], by[s], bth[s], wx, wy, wth);
+                part[1] += load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(wx, wy, wth);
+                // capacitance: G_l,j = sigma [[Rg, kv],[0,1]]
+                const Sym3 sg = load_sym3(P.chain, P.estride, F_SG, ek[s]);
+                double Gm[NL][3][3];
+                const int j = jbase + s * 64;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const LoopConst& q = sh.lc[l];
+                    const LoopState& st = sh.ls[cur][l];
+                    const bool on = j > q.lo && j <= q.hi;
+                    const double sgn = on ? q.sigma : 0.0;
+                    const double cf = st.pf[3], sf = st.pf[4];
+                    const double cq = cf * cP[s] + sf * sP[s], sq = cf * sP[s] - sf * cP[s];
+                    const double cR = q.cz * cq + q.sz * sq, sR = q.cz * sq - q.sz * cq;
+                    const double jx = -(st.pt[1] - X[s].y), jy = (st.pt[0] - X[s].x);
+                    const double fx = cf * jx + sf * jy, fy = -sf * jx + cf * jy;
+                    const double kx = q.cz * fx + q.sz * fy, ky = -q.sz * fx + q.cz * fy;
+                    Gc[s][l][0] = cR; Gc[s][l][1] = sR; Gc[s][l][2] = kx; Gc[s][l][3] = ky; Gc[s][l][4] = sgn;
+                    Gm[l][0][0] = sgn * cR; Gm[l][0][1] = -sgn * sR; Gm[l][0][2] = sgn * kx;
+                    Gm[l][1][0] = sgn * sR; Gm[l][1][1] = sgn * cR;  Gm[l][1][2] = sgn * ky;
+                    Gm[l][2][0] = 0.0;      Gm[l][2][1] = 0.0;       Gm[l][2][2] = sgn;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        part[2 + l * 3 + r] += Gm[l][r][0] * ex[s] + Gm[l][r][1] * ey[s] + Gm[l][r][2] * eth[s];
+                }
+                double Hm[NL][3][3];
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double g0 = Gm[l][r][0], g1 = Gm[l][r][1], g2 = Gm[l][r][2];
+                        Hm[l][r][0] = g0 * sg.a00 + g1 * sg.a01 + g2 * sg.a02;
+                        Hm[l][r][1] = g0 * sg.a01 + g1 * sg.a11 + g2 * sg.a12;
+                        Hm[l][r][2] = g0 * sg.a02 + g1 * sg.a12 + g2 * sg.a22;
+                    }
+                int idx = 2 + NS;
+#pragma unroll
+                for (int r = 0; r < NS; ++r)
+#pragma unroll
+                    for (int c = r; c < NS; ++c) {
+                        const int l1 = r / 3, r1 = r % 3, l2 = c / 3, r2 = c % 3;
+                        part[idx] += Hm[l1][r1][0] * Gm[l2][r2][0] + Hm[l1][r1][1] * Gm[l2][r2][1] +
+                                     Hm[l1][r1][2] * Gm[l2][r2][2];
+                        ++idx;
+                    }
+            }
+            if (tid < NL) part[1] += loop_quad(tid, S);
+            ++phase;
+            reduce(part, sh.scr[phase & 1]);
+            ++phase;
+            bb = part[0];
+            bHb = part[1];
+            alpha = bb / bHb;
+            hsdNorm = sqrt(alpha * alpha * bb);
+            int idx = 2 + NS;
+#pragma unroll
+            for (int r = 0; r < NS; ++r)
+#pragma unroll
+                for (int c = r; c < NS; ++c) { S6[r][c] = part[idx]; S6[c][r] = part[idx]; ++idx; }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const LoopConst& q = sh.lc[l];
+                const LoopState& st = sh.ls[cur][l];
+                S6[3 * l + 0][3 * l + 0] += q.sg[0]; S6[3 * l + 0][3 * l + 1] += q.sg[1]; S6[3 * l + 0][3 * l + 2] += q.sg[2];
+                S6[3 * l + 1][3 * l + 0] += q.sg[1]; S6[3 * l + 1][3 * l + 1] += q.sg[3]; S6[3 * l + 1][3 * l + 2] += q.sg[4];
+                S6[3 * l + 2][3 * l + 0] += q.sg[2]; S6[3 * l + 2][3 * l + 1] += q.sg[4]; S6[3 * l + 2][3 * l + 2] += q.sg[5];
+                mu[3 * l + 0] = st.e[0] - part[2 + 3 * l + 0];
+                mu[3 * l + 1] = st.e[1] - part[2 + 3 * l + 1];
+                mu[3 * l + 2] = st.e[2] - part[2 + 3 * l + 2];
+            }
+        }
+        if (!chol_solve<NS>(S6, mu)) { flags |= 2; break; }
+
+        // ---- phase I3: u, rho, prefix sums -> h_gn ----
+        {
+            double rx_[M], ry_[M], rth_[M];
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                rx_[s] = ry_[s] = rth_[s] = 0.0;
+                if (!valid[s]) continue;
+                double wx = 0.0, wy = 0.0, wth = 0.0;  // sum_l G^T mu
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double cR = Gc[s][l][0], sR = Gc[s][l][1], kx = Gc[s][l][2], ky = Gc[s][l][3], sgn = Gc[s][l][4];
+                    const double m0 = mu[3 * l], m1 = mu[3 * l + 1], m2 = mu[3 * l + 2];
+                    wx += sgn * (cR * m0 + sR * m1);
+                    wy += sgn * (-sR * m0 + cR * m1);
+                    wth += sgn * (kx * m0 + ky * m1 + m2);
+                }
+                double vx, vy, vth;
+                load_sym3(P.chain, P.estride, F_SG, ek[s]).mul(wx, wy, wth, vx, vy, vth);
+                const double ux = -vx - ex[s], uy = -vy - ey[s], uth = -vth - eth[s];
+                rx_[s] = cP[s] * ux - sP[s] * uy;
+                ry_[s] = sP[s] * ux + cP[s] * uy;
+                rth_[s] = uth;
+            }
+            // wave-local inclusive scans in pose order (slot after slot), theta first
+            double lth[M], carry = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                lth[s] = wave_inclusive_scan(rth_[s]) + carry;
+                carry = read_lane(lth[s], 63);
+            }
+            const double thTot = carry;
+            // term = rho_t + J dt * h_theta(j-1), with the wave-local part of h_theta
+            double lx_[M], ly_[M], cx = 0.0, cy = 0.0, cprev = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const double thPrev = lane_prev(lth[s], cprev);      // wave-local h_theta(j-1)
+                cprev = read_lane(lth[s], 63);
+                double tx = 0.0, ty = 0.0;
+                if (valid[s]) {
+                    const double dx = X[s].x - A[s].x, dy = X[s].y - A[s].y;
+                    tx = rx_[s] - dy * thPrev;
+                    ty = ry_[s] + dx * thPrev;
+                }
+                lx_[s] = wave_inclusive_scan(tx) + cx;
+                ly_[s] = wave_inclusive_scan(ty) + cy;
+                cx = read_lane(lx_[s], 63); cy = read_lane(ly_[s], 63);
+            }
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            // cross-wave correction: h_t(j) += base_t(w) + J (t_j - t_start(w)) * base_theta(w)
+            const double sx0 = read_lane(A[0].x, 0), sy0 = read_lane(A[0].y, 0);
+            double lastx = sx0, lasty = sy0;          // last valid pose of the wave
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const unsigned long long vm = __ballot(valid[s]);
+                if (vm) {
+                    const int ll = 63 - __clzll((long long)vm);
+                    lastx = read_lane(X[s].x, ll); lasty = read_lane(X[s].y, ll);
+                }
+            }
+            if (lane == 0) {
+                S.scan[wave][0] = thTot; S.scan[wave][1] = cx; S.scan[wave][2] = cy;
+                S.scan[wave][3] = lastx - sx0; S.scan[wave][4] = lasty - sy0;
+            }
+            __syncthreads();
+            double bth_ = 0.0, bxx = 0.0, byy = 0.0;       // bases of this wave
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                if (w < wave) {
+                    bxx += S.scan[w][1] - S.scan[w][4] * bth_;
+                    byy += S.scan[w][2] + S.scan[w][3] * bth_;
+                    bth_ += S.scan[w][0];
+                }
+            }
+            ++phase;
+            double nrm[1] = {0.0};
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                if (!valid[s]) { hx[s] = hy[s] = hth[s] = 0.0; continue; }
+                hth[s] = lth[s] + bth_;
+                hx[s] = lx_[s] + bxx - (X[s].y - sy0) * bth_;
+                hy[s] = ly_[s] + byy + (X[s].x - sx0) * bth_;
+                nrm[0] += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
+            }
+            reduce(nrm, sh.scr[phase & 1]);
+            ++phase;
+            hgnNorm = sqrt(nrm[0]);
+        }
+
+        // ---- trial loop ----
+        bool goodStep = false;
+        int numTries = 0;
+        do {
+            ++numTries;
+            int stepType;                             // 0 GN, 1 SD, 2 DL
+            double beta = 0.0, sdScale = 0.0;
+            if (hgnNorm < delta) stepType = 0;
+            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
+            else {
+                stepType = 2;
+                double part[2] = {0.0, 0.0};          // c = hsd.(hgn-hsd), |hgn-hsd|^2
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    if (!valid[s]) continue;
+                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
+                    const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
+                    part[0] += sx * ax + sy * ay + sth * ath;
+                    part[1] += ax * ax + ay * ay + ath * ath;
+                }
+                reduce(part, sh.scr[phase & 1]);
+                ++phase;
+                const double c = part[0], bma = part[1], hsdSq = alpha * alpha * bb;
+                if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
+                else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
+            }
+            // step, trial poses, publish
+            double dlx[M], dly[M], dlth[M];
+            bool changed = false;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                if (stepType == 0) { dlx[s] = hx[s]; dly[s] = hy[s]; dlth[s] = hth[s]; }
+                else if (stepType == 1) {
+                    dlx[s] = sdScale * (alpha * bx[s]); dly[s] = sdScale * (alpha * by[s]); dlth[s] = sdScale * (alpha * bth[s]);
+                } else {
+                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
+                    dlx[s] = sx + beta * (hx[s] - sx); dly[s] = sy + beta * (hy[s] - sy); dlth[s] = sth + beta * (hth[s] - sth);
+                }
+                if (!valid[s]) { dlx[s] = dly[s] = dlth[s] = 0.0; Xn[s] = X[s]; continue; }
+                Xn[s].x = X[s].x + dlx[s];
+                Xn[s].y = X[s].y + dly[s];
+                Xn[s].th = normalize_theta(X[s].th + dlth[s]);
+                sincos(Xn[s].th, &Xn[s].s, &Xn[s].c);
+                changed |= (Xn[s].x != X[s].x) || (Xn[s].y != X[s].y) || (Xn[s].th != X[s].th);
+            }
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            const int trial = cur ^ 1;
+            publish_poses(Xn, S, trial);
+            publish_vec(dlx, dly, dlth, S);
+            __syncthreads();
+            // linear gain pieces + trial errors in one pass
+            double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // hdl^T H hdl, b.hdl, |hdl|^2, newChi, changed
+            {
+                Pose2 An[M];
+                prev_pose(Xn, edge_pose_of(S), An);
+                double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+                if (wave > 0) { e0 = S.hi_vec[wave - 1][0]; e1 = S.hi_vec[wave - 1][1]; e2 = S.hi_vec[wave - 1][2]; }
+                double pdx[M], pdy[M], pdth[M];
+                prev_vec(dlx, dly, dlth, e0, e1, e2, pdx, pdy, pdth);
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    if (!valid[s]) continue;
+                    const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                    const Sym3 om = load_sym3(P.chain, P.estride, F_OM, ek[s]);
+                    double wx, wy, wth;
+                    se2_apply_J(A[s], X[s], cz, sz, pdx[s], pdy[s], pdth[s], dlx[s], dly[s], dlth[s], wx, wy, wth);
+                    part[0] += om.quad(wx, wy, wth);
+                    part[1] += bx[s] * dlx[s] + by[s] * dly[s] + bth[s] * dlth[s];
+                    part[2] += dlx[s] * dlx[s] + dly[s] * dly[s] + dlth[s] * dlth[s];
+                    se2_error(An[s], Xn[s], ldc(F_TZX, s), ldc(F_TZY, s), cz, sz, ldc(F_THZ, s), enx[s], eny[s], enth[s]);
+                    part[3] += om.quad(enx[s], eny[s], enth[s]);
+                }
+                if (tid < NL) { part[0] += loop_quad(tid, S); part[3] += loop_eval(tid, trial); }
+                if (changed) part[4] = 1.0;
+            }
+            ++phase;
+            reduce(part, sh.scr[phase & 1]);
+            ++phase;
+            ++evals;
+            double linearGain = -1 * part[0] + 2 * part[1];
+            const double hdlNorm = sqrt(part[2]);
+            const double newChi = part[3];
+            const bool anyChanged = part[4] != 0.0;
+            const double nonLinearGain = currentChi - newChi;
+            if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
+            const double rho = nonLinearGain / linearGain;
+            if (rho > 0) {                            // discardTop: commit the trial
+                goodStep = true;
+                currentChi = newChi;
+                cur = trial;
+#pragma unroll
+                for (int s = 0; s < M; ++s) { X[s] = Xn[s]; ex[s] = enx[s]; ey[s] = eny[s]; eth[s] = enth[s]; }
+            }
+            if (rho > 0.75) delta = fmax(delta, 3 * hdlNorm);
+            else if (rho < 0.25) delta *= 0.5;
+            if (!goodStep) {
+                if (stepType == 0) {
+                    // identical GN trial repeats while hgnNorm < delta: each halves delta
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                } else if (stepType == 1 && !anyChanged) {
+                    numTries = maxTrials;             // every later (halved) SD step is a no-op too
+                }
+            }
+        } while (!goodStep && numTries < maxTrials);
+        it_done = it + 1;
+        tries_total += numTries;
+        if (numTries == maxTrials || !goodStep) { flags |= 1; break; }
+    }
+
+    // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
+    double mx = 0.0;
+    bool nan = false;
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        if (!valid[s]) continue;
+        const double c = load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(ex[s], ey[s], eth[s]);
+        if (c != c) nan = true;
+        else mx = fmax(mx, c);
+    }
+    mx = wave_max(mx);
+    {
+        Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+        const unsigned long long nb = __ballot(nan);
+        if (lane == 0) { S.red[wave][0] = mx; S.red[wave][1] = nb ? 1.0 : 0.0; }
+        __syncthreads();
+        double m2 = S.red[0][0], nn = S.red[0][1];
+#pragma unroll
+        for (int w = 1; w < W; ++w) { m2 = fmax(m2, S.red[w][0]); nn += S.red[w][1]; }
+        mx = m2;
+        nan = nn != 0.0;
+        ++phase;
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const double c = sh.ls[cur][l].chi;
+        if (c != c) nan = true;
+        else mx = fmax(mx, c);
+    }
+    // a NaN chi2 must survive: g2o's "chi2 > th" is false for NaN
+    if (nan) mx = __longlong_as_double(0x7ff8000000000000ll);
+    res.max_chi2 = mx;
+    res.chi2_total = currentChi;
+    res.iterations = it_done;
+    res.tries = tries_total;
+    res.flags = flags;
+    res.evals = evals;
+}
+
+}  // namespace ipc
