@@ -50,10 +50,11 @@ extern "C" const char* ipc_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------
 struct Variant { int W, M; };                   // waves per cell, poses per lane
 static const Variant kVariants[] = {
-    {1, 1}, {2, 1}, {4, 1}, {6, 1}, {8, 1}, {12, 1}, {16, 1}, {12, 2}, {16, 2}, {16, 4}, {16, 8}, {16, 16},
+    {1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1}, {10, 1}, {12, 1}, {14, 1}, {16, 1},
+    {16, 2}, {16, 4}, {16, 8}, {16, 16},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kMaxBins = 16;
+constexpr int kMaxBins = 20;
 struct BinCaps { int n; int cap[kMaxBins]; };
 
 __device__ __forceinline__ int bin_of(const BinCaps& bc, int L)
@@ -169,8 +170,13 @@ struct CellOut {
     int4* meta;               // iterations, tries, flags, error evaluations
 };
 
+// M == 1 variants are held to 128 VGPRs (4 waves per SIMD => 16 waves per CU: two 8-wave cells
+// or four 4-wave cells in flight per CU, so one cell's barrier waits hide behind another's work)
+#ifndef IPC_MINW
+#define IPC_MINW 1
+#endif
 template <int W, int M, int NL>
-__global__ __launch_bounds__(64 * W) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
+__global__ __launch_bounds__(64 * W, (M == 1 ? IPC_MINW : 1)) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
                                                            SolveParams prm, CellOut out)
 {
     __shared__ Se2Shared<W, M, NL> sh;
@@ -204,18 +210,26 @@ static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& 
         hipLaunchKernelGGL((se2_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
         break;
     switch (variant) {
+#ifdef IPC_DEBUG_ONE_VARIANT
+        IPC_CASE(8, 10, 1)
+#else
         IPC_CASE(0, 1, 1)
         IPC_CASE(1, 2, 1)
-        IPC_CASE(2, 4, 1)
-        IPC_CASE(3, 6, 1)
-        IPC_CASE(4, 8, 1)
-        IPC_CASE(5, 12, 1)
-        IPC_CASE(6, 16, 1)
-        IPC_CASE(7, 12, 2)
-        IPC_CASE(8, 16, 2)
-        IPC_CASE(9, 16, 4)
-        IPC_CASE(10, 16, 8)
-        IPC_CASE(11, 16, 16)
+        IPC_CASE(2, 3, 1)
+        IPC_CASE(3, 4, 1)
+        IPC_CASE(4, 5, 1)
+        IPC_CASE(5, 6, 1)
+        IPC_CASE(6, 7, 1)
+        IPC_CASE(7, 8, 1)
+        IPC_CASE(8, 10, 1)
+        IPC_CASE(9, 12, 1)
+        IPC_CASE(10, 14, 1)
+        IPC_CASE(11, 16, 1)
+        IPC_CASE(12, 16, 2)
+        IPC_CASE(13, 16, 4)
+        IPC_CASE(14, 16, 8)
+        IPC_CASE(15, 16, 16)
+#endif
         default: return hipErrorInvalidValue;
     }
 #undef IPC_CASE
@@ -489,6 +503,12 @@ static Se2View make_view(const ipc_engine* h)
     Se2View P;
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
+    P.dbg = nullptr;
+#ifdef DBG_SIDE
+    static double* dbgbuf = nullptr;
+    if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
+    P.dbg = dbgbuf;
+#endif
     return P;
 }
 
@@ -663,6 +683,15 @@ extern "C" int ipc_solver_time_ms(ipc_engine_t* h, double* ms, int* launches)
     return IPC_OK;
 }
 
+#ifdef DBG_SIDE
+extern "C" int ipc_dbg_read(ipc_engine_t* h, double* out, int n)
+{
+    Se2View P = make_view(h);
+    hipDeviceSynchronize();
+    hipMemcpy(out, P.dbg, sizeof(double) * n, hipMemcpyDeviceToHost);
+    return 0;
+}
+#endif
 extern "C" int ipc_synchronize(ipc_engine_t* h)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_synchronize: NULL handle");

@@ -31,9 +31,15 @@
 //       - a steepest-descent trial whose update leaves every pose bit-identical has
 //         newChi == currentChi (rho = 0, rejected) and so have all later, halved ones: the
 //         trial counter is fast-forwarded to Terminate.
+//   * The dog-leg's linear gain  -h^T H h + 2 b^T h  of a trial step is assembled from four
+//     per-iteration scalars (b^T b, b^T H b, b^T h_gn, h_gn^T H h_gn; b^T H h_gn = b^T b because
+//     H h_gn = b), since every trial step is a combination of b and h_gn.  A trial therefore
+//     costs one residual pass and ONE reduced scalar (the new chi2).
 //   * Every phase is: element-wise work -> one __syncthreads -> read what the other waves
 //     published.  All LDS scratch is double buffered on the phase parity, which makes one
-//     barrier per phase sufficient.
+//     barrier per phase sufficient.  Wide reductions (the 11 / 29 capacitance partials) use
+//     gfx950's v_permlane32_swap / v_permlane16_swap to reduce four values per register, and
+//     the 6x6 capacitance solve runs on wave 0 only.
 #pragma once
 #include "block_prims.hpp"
 
@@ -53,6 +59,7 @@ struct Se2View {
     int cstride;
     const int* cand_from;     // candidate "from" / "to" vertex ids
     const int* cand_to;
+    double* dbg;              // debug side channel (NULL in production)
 };
 
 struct SolveParams {
@@ -67,6 +74,42 @@ __device__ __forceinline__ double normalize_theta(double theta)
     if (theta >= kPi) theta -= 2 * kPi;
     if (theta < -kPi) theta += 2 * kPi;
     return theta;
+}
+
+// sin/cos for |theta| <= pi (every pose angle is kept normalised to [-pi, pi)): Cody-Waite
+// reduction by multiples of pi/2 (two-term, exact with FMA for |n| <= 2) and the classic
+// degree-13/14 minimax kernels on [-pi/4, pi/4].  Branch-free, ~45 VALU ops, absolute error
+// < 1.2e-16 -- OCML's sincos carries a Payne-Hanek large-argument path that costs ~60 VGPRs we
+// need elsewhere.
+__device__ __forceinline__ void sincos_pi(double th, double& sn, double& cs)
+{
+#ifdef DBG_OLD_SINCOS
+    sincos(th, &sn, &cs);
+    return;
+#endif
+    const double n = rint(th * 6.36619772367581382433e-01);            // th * 2/pi
+    double r = fma(-n, 1.57079632673412561417e+00, th);                // pio2_1 (33 bits)
+    r = fma(-n, 6.07710050650619224932e-11, r);                        // pio2_1t
+    const double z = r * r;
+    // sin kernel
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double sr = fma(z * r, fma(z, rs, S1), r);
+    // cos kernel
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * rc);
+    const int q = ((int)n) & 3;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
 struct Sym3 {                 // symmetric 3x3: 00 01 02 11 12 22
@@ -177,28 +220,6 @@ struct CellResult {
     int evals;                // trial evaluations (sincos + residual passes) executed
 };
 
-// ---- lane-neighbour moves (DPP, full rate; no LDS) ----
-// value of lane-1; lane 0 receives `carry`
-__device__ __forceinline__ double lane_prev(double v, double carry)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(carry), __double2loint(v), 0x138, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// value of lane+1; lane 63 receives `carry`
-__device__ __forceinline__ double lane_next(double v, double carry)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(carry), __double2loint(v), 0x130, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(carry), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double read_lane(double v, int l)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // loop-closure edge: constants and per-state values, all in LDS (uniform data)
 struct LoopConst {
     int f, t, lo, hi;         // local pose indices 0..L; lo/hi = min/max(f,t)
@@ -215,12 +236,13 @@ struct LoopState {
 
 template <int W, int NL>
 struct Se2Scratch {           // per-phase hand-off, double buffered
-    double red[W][32];        // per-wave partial sums
+    double red[32 * 16];      // wide reductions: [wave][32]; narrow ones: [value][16 waves]
     double hi_pose[W][5];     // pose held by lane 63 / last slot of each wave
     double hi_vec[W][3];      // vector held by lane 63 / last slot
     double lo_vec[W][3];      // vector held by lane 0 / slot 0
     double lvec[NL][2][3];    // vectors at the loop end points (from, to)
     double scan[W][5];        // per-wave scan totals
+    double sol[NL * 3 + 3];   // capacitance solution mu, b^T b, b^T H b, ok flag (written by wave 0)
 };
 
 template <int W, int M, int NL>
@@ -235,6 +257,8 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                                Se2Shared<W, M, NL>& sh, CellResult& res)
 {
     constexpr int NS = NL * 3;
+    constexpr int KR = 2 + NS + NS * (NS + 1) / 2;   // b^T b, b^T H b, d, S (upper triangle)
+    static_assert(KR <= 32 && W <= 16, "reduction scratch layout");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jbase = 1 + wave * 64 * M + lane;      // pose index of slot 0
 
@@ -272,7 +296,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     gauge.x = P.pose0[lo_abs];
     gauge.y = P.pose0[(size_t)P.V + lo_abs];
     gauge.th = P.pose0[(size_t)2 * P.V + lo_abs];
-    sincos(gauge.th, &gauge.s, &gauge.c);
+    sincos_pi(gauge.th, gauge.s, gauge.c);
 #pragma unroll
     for (int s = 0; s < M; ++s) {
         const int j = jbase + s * 64;
@@ -282,7 +306,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         Xn[s].x = P.pose0[ja];
         Xn[s].y = P.pose0[(size_t)P.V + ja];
         Xn[s].th = P.pose0[(size_t)2 * P.V + ja];
-        sincos(Xn[s].th, &Xn[s].s, &Xn[s].c);
+        sincos_pi(Xn[s].th, Xn[s].s, Xn[s].c);
         X[s] = Xn[s];
         hx[s] = hy[s] = hth[s] = 0.0;
         bx[s] = by[s] = bth[s] = 0.0;
@@ -292,7 +316,10 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     __syncthreads();                                 // sh.lc visible
     int lf[NL], lt[NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) { lf[l] = sh.lc[l].f; lt[l] = sh.lc[l].t; }
+    for (int l = 0; l < NL; ++l) {
+        lf[l] = __builtin_amdgcn_readfirstlane(sh.lc[l].f);
+        lt[l] = __builtin_amdgcn_readfirstlane(sh.lc[l].t);
+    }
     // gauge end points never change: write them into both state buffers once
     if (tid == 0) {
 #pragma unroll
@@ -306,12 +333,35 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             }
     }
 
-    auto ldc = [&](int field, int s) { return P.chain[(size_t)field * P.estride + ek[s]]; };
+    // The chain constants are deliberately re-read where used (coalesced, L1/L2 resident):
+    // keeping all 17 per slot would cost 34 VGPRs per pose.  Loads use a uniform (SGPR) field
+    // base + one 32-bit byte offset per slot, so no 64-bit per-field addresses are kept alive.
+    // opaque() stops the compiler from hoisting those loads out of the iteration loop.
+    unsigned eoff[M];
+#pragma unroll
+    for (int s = 0; s < M; ++s) eoff[s] = (unsigned)ek[s] << 3;
+    // (the per-field bases are recomputed from `fstride` with two SALU ops per use instead of
+    // pinning 17 SGPR pairs: the kernel is SGPR-bound otherwise)
+    unsigned fstride = (unsigned)P.estride << 3;      // bytes between two fields
+    auto opaque = [&]() {
+#pragma unroll
+        for (int s = 0; s < M; ++s) asm volatile("" : "+v"(eoff[s]));
+    };
+    auto ldc = [&](int field, int s) -> double {
+        const char* fb = reinterpret_cast<const char*>(P.chain) + (size_t)field * fstride;
+        return *reinterpret_cast<const double*>(fb + eoff[s]);
+    };
+    auto ldsym = [&](int field0, int s) -> Sym3 {
+        Sym3 m;
+        m.a00 = ldc(field0 + 0, s); m.a01 = ldc(field0 + 1, s); m.a02 = ldc(field0 + 2, s);
+        m.a11 = ldc(field0 + 3, s); m.a12 = ldc(field0 + 4, s); m.a22 = ldc(field0 + 5, s);
+        return m;
+    };
 
     int phase = 0;                                   // scratch parity
     int cur = 0;                                     // committed loop-state buffer
 
-    // pose of chain neighbour j-1 for every slot, from poses Y (DPP + wave-boundary value `edge`)
+    // pose of chain neighbour j-1 for every slot, from poses Y (DPP + wave-boundary pose `edge`)
     auto prev_pose = [&](const Pose2 (&Y)[M], const Pose2& edge, Pose2 (&A)[M]) {
         Pose2 carry = edge;
 #pragma unroll
@@ -321,17 +371,10 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             A[s].th = lane_prev(Y[s].th, carry.th);
             A[s].c = lane_prev(Y[s].c, carry.c);
             A[s].s = lane_prev(Y[s].s, carry.s);
-            carry.x = read_lane(Y[s].x, 63); carry.y = read_lane(Y[s].y, 63); carry.th = read_lane(Y[s].th, 63);
-            carry.c = read_lane(Y[s].c, 63); carry.s = read_lane(Y[s].s, 63);
-        }
-    };
-    auto prev_vec = [&](const double (&vx)[M], const double (&vy)[M], const double (&vth)[M], double e0,
-                        double e1, double e2, double (&ax)[M], double (&ay)[M], double (&ath)[M]) {
-        double c0 = e0, c1 = e1, c2 = e2;
-#pragma unroll
-        for (int s = 0; s < M; ++s) {
-            ax[s] = lane_prev(vx[s], c0); ay[s] = lane_prev(vy[s], c1); ath[s] = lane_prev(vth[s], c2);
-            c0 = read_lane(vx[s], 63); c1 = read_lane(vy[s], 63); c2 = read_lane(vth[s], 63);
+            if (s + 1 < M) {
+                carry.x = read_lane(Y[s].x, 63); carry.y = read_lane(Y[s].y, 63); carry.th = read_lane(Y[s].th, 63);
+                carry.c = read_lane(Y[s].c, 63); carry.s = read_lane(Y[s].s, 63);
+            }
         }
     };
     // publish the wave's last pose (lane 63, slot M-1) and the loop end points of poses Y
@@ -355,9 +398,9 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
             }
     };
-    auto publish_vec = [&](const double (&vx)[M], const double (&vy)[M], const double (&vth)[M],
-                           Se2Scratch<W, NL>& S) {
-        if (lane == 63) { S.hi_vec[wave][0] = vx[M - 1]; S.hi_vec[wave][1] = vy[M - 1]; S.hi_vec[wave][2] = vth[M - 1]; }
+    // publish a per-pose vector at the loop end points (the gauge end point carries zero)
+    auto publish_endpoint_vec = [&](const double (&vx)[M], const double (&vy)[M], const double (&vth)[M],
+                                    Se2Scratch<W, NL>& S) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (tid == 0) {
@@ -373,30 +416,13 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         }
     };
     auto edge_pose_of = [&](const Se2Scratch<W, NL>& S) -> Pose2 {
-        if (wave == 0) return gauge;
-        Pose2 p;
-        p.x = S.hi_pose[wave - 1][0]; p.y = S.hi_pose[wave - 1][1]; p.th = S.hi_pose[wave - 1][2];
-        p.c = S.hi_pose[wave - 1][3]; p.s = S.hi_pose[wave - 1][4];
+        Pose2 p = gauge;
+        if (wave > 0) {
+            p.x = S.hi_pose[wave - 1][0]; p.y = S.hi_pose[wave - 1][1]; p.th = S.hi_pose[wave - 1][2];
+            p.c = S.hi_pose[wave - 1][3]; p.s = S.hi_pose[wave - 1][4];
+        }
+        p.x = uni(p.x); p.y = uni(p.y); p.th = uni(p.th); p.c = uni(p.c); p.s = uni(p.s);
         return p;
-    };
-    // workgroup sum of K partials: DPP wave sum, lane 0 -> LDS, ONE barrier, all read.
-    // The barrier also orders everything published into the scratch / loop-state buffers before.
-    auto reduce = [&](auto& part, Se2Scratch<W, NL>& S) {
-        constexpr int K = sizeof(part) / sizeof(double);
-#pragma unroll
-        for (int k = 0; k < K; ++k) part[k] = wave_sum(part[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) S.red[wave][k] = part[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double acc = S.red[0][k];
-#pragma unroll
-            for (int w = 1; w < W; ++w) acc += S.red[w][k];
-            part[k] = acc;
-        }
     };
 
     // loop l: error / force / chi2 from its end-point poses in state buffer `bsel` (one lane)
@@ -417,7 +443,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         st.chi = chi;
         return chi;
     };
-    // loop l: w^T Om w with w = J_l applied to the end-point vectors in S.lvec (one lane)
+    // loop l: w^T Om w with w = J_l applied to the end-point vectors in S.lvec (uniform data)
     auto loop_quad = [&](int l, const Se2Scratch<W, NL>& S) -> double {
         const LoopConst& q = sh.lc[l];
         const LoopState& st = sh.ls[cur][l];
@@ -430,47 +456,68 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         return om.quad(wx, wy, wth);
     };
 
+    // One residual pass over poses Y: publishes the hand-off values, computes the odometry errors
+    // into (ox,oy,oth) and the loop state into buffer `bsel`; returns total chi2 and whether any
+    // lane flagged `changed`.  Two barriers.
+    Pose2 edge = gauge;                              // committed pose of this wave's predecessor
+    Pose2 edgeN = gauge;                             // same for the trial state
+    auto evaluate = [&](const Pose2 (&Y)[M], double (&ox)[M], double (&oy)[M], double (&oth)[M], int bsel,
+                        bool changed, bool& anyChanged) -> double {
+        Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+        publish_poses(Y, S, bsel);
+        __syncthreads();
+        edgeN = edge_pose_of(S);
+        ++phase;
+        Pose2 An[M];
+        prev_pose(Y, edgeN, An);
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            if (!valid[s]) continue;
+            se2_error(An[s], Y[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s),
+                      ox[s], oy[s], oth[s]);
+            part += ldsym(F_OM, s).quad(ox[s], oy[s], oth[s]);
+        }
+        if (tid < NL) part += loop_eval(tid, bsel);
+        part = wave_sum(part);
+        const bool wchg = __ballot(changed) != 0ull;
+        Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
+        if (lane == 0) { S2.red[wave] = part; S2.red[16 + wave] = wchg ? 1.0 : 0.0; }
+        __syncthreads();
+        double tot[2];
+        gather_totals<2>(S2.red, W, tot);
+        ++phase;
+        anyChanged = tot[1] != 0.0;
+        return tot[0];
+    };
+
     // ---------------- initial errors (consensus_utils.cpp:11) ----------------
     int evals = 0;
     double currentChi;
     {
-        Se2Scratch<W, NL>& S = sh.scr[phase & 1];
-        publish_poses(X, S, cur);
-        __syncthreads();
-        Pose2 A0[M];
-        prev_pose(X, edge_pose_of(S), A0);
-        double part[1] = {0.0};
-#pragma unroll
-        for (int s = 0; s < M; ++s) {
-            if (!valid[s]) continue;
-            se2_error(A0[s], X[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s),
-                      ex[s], ey[s], eth[s]);
-            part[0] += load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(ex[s], ey[s], eth[s]);
-        }
-        if (tid < NL) part[0] += loop_eval(tid, cur);
-        ++phase;
-        reduce(part, sh.scr[phase & 1]);
-        ++phase;
-        currentChi = part[0];
+        bool dummy;
+        currentChi = evaluate(X, ex, ey, eth, cur, false, dummy);
+        edge = edgeN;
         ++evals;
     }
 
     // ---------------- dog-leg (g2o OptimizationAlgorithmDogleg::solve) ----------------
+#ifdef DBG_DUMP3
+    double dbg0 = 0, dbg1 = 0, dbg2 = 0, dbg3 = 0;
+#endif
     double delta = 1e4;
     const int maxTrials = 100;
     int it_done = 0, tries_total = 0, flags = 0;
 
     for (int it = 0; it < iterations; ++it) {
-        // committed poses X, errors e and loop state ls[cur] are consistent here
+        opaque();
+        // committed poses X (+ edge), errors e and loop state ls[cur] are consistent here
         Pose2 A[M];                                  // committed pose j-1 per slot
+        prev_pose(X, edge, A);
         double cP[M], sP[M];                         // P_j = R_{j-1} Rz_j
-        // ---- phase I1: forces g, hand-back m; b ----
+        // ---- phase A: forces g, hand-back m -> b ----
+        double pbx, pby, pbth;                        // b of this wave's predecessor pose (uniform)
         {
-            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
-            publish_poses(X, S, cur);
-            __syncthreads();
-            prev_pose(X, edge_pose_of(S), A);
-            ++phase;
             double gx[M], gy[M], gth[M], mx[M], my[M], mth[M];
 #pragma unroll
             for (int s = 0; s < M; ++s) {
@@ -481,7 +528,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 cP[s] = A[s].c * cz - A[s].s * sz;
                 sP[s] = A[s].s * cz + A[s].c * sz;
                 double qx, qy, qth;
-                load_sym3(P.chain, P.estride, F_OM, ek[s]).mul(ex[s], ey[s], eth[s], qx, qy, qth);
+                ldsym(F_OM, s).mul(ex[s], ey[s], eth[s], qx, qy, qth);
                 gx[s] = cP[s] * qx - sP[s] * qy;
                 gy[s] = sP[s] * qx + cP[s] * qy;
                 gth[s] = qth;
@@ -489,17 +536,36 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 mx[s] = gx[s]; my[s] = gy[s];
                 mth[s] = gth[s] + (-dy * gx[s] + dx * gy[s]);
             }
-            Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
-            if (lane == 0) { S2.lo_vec[wave][0] = mx[0]; S2.lo_vec[wave][1] = my[0]; S2.lo_vec[wave][2] = mth[0]; }
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            if (lane == 0) { S.lo_vec[wave][0] = mx[0]; S.lo_vec[wave][1] = my[0]; S.lo_vec[wave][2] = mth[0]; }
+            if (lane == 63) { S.hi_vec[wave][0] = gx[M - 1]; S.hi_vec[wave][1] = gy[M - 1]; S.hi_vec[wave][2] = gth[M - 1]; }
             __syncthreads();
             // m of pose j+1: next lane / next slot's lane 0 / next wave's lane 0
             double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-            if (wave + 1 < W) { n0 = S2.lo_vec[wave + 1][0]; n1 = S2.lo_vec[wave + 1][1]; n2 = S2.lo_vec[wave + 1][2]; }
+            if (wave + 1 < W) { n0 = S.lo_vec[wave + 1][0]; n1 = S.lo_vec[wave + 1][1]; n2 = S.lo_vec[wave + 1][2]; }
+            // b of the predecessor pose jp = jbase0 - 1 (zero for the gauge): m(jp+1) - g(jp) + loops
+            pbx = pby = pbth = 0.0;
+            if (wave > 0) {
+                pbx = read_lane(mx[0], 0) - S.hi_vec[wave - 1][0];
+                pby = read_lane(my[0], 0) - S.hi_vec[wave - 1][1];
+                pbth = read_lane(mth[0], 0) - S.hi_vec[wave - 1][2];
+                const int jp = wave * 64 * M;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const LoopState& st = sh.ls[cur][l];
+                    if (jp == lt[l]) { pbx -= st.g[0]; pby -= st.g[1]; pbth -= st.g[2]; }
+                    if (jp == lf[l]) {
+                        const double dx = st.pt[0] - st.pf[0], dy = st.pt[1] - st.pf[1];
+                        pbx += st.g[0]; pby += st.g[1];
+                        pbth += st.g[2] + (-dy * st.g[0] + dx * st.g[1]);
+                    }
+                }
+            }
             ++phase;
 #pragma unroll
             for (int s = M - 1; s >= 0; --s) {
                 const double ux = lane_next(mx[s], n0), uy = lane_next(my[s], n1), uth = lane_next(mth[s], n2);
-                n0 = read_lane(mx[s], 0); n1 = read_lane(my[s], 0); n2 = read_lane(mth[s], 0);
+                if (s > 0) { n0 = read_lane(mx[s], 0); n1 = read_lane(my[s], 0); n2 = read_lane(mth[s], 0); }
                 // invalid slots hold m = 0, so poses past the end contribute nothing
                 bx[s] = ux - gx[s]; by[s] = uy - gy[s]; bth[s] = uth - gth[s];
                 if (!valid[s]) { bx[s] = by[s] = bth[s] = 0.0; }
@@ -519,105 +585,185 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
             }
         }
-        // ---- phase I2: b^T b, b^T H b, capacitance partials ----
-        double bb, bHb, alpha, hsdNorm, hgnNorm;
+        // ---- phase B: b^T b, b^T H b, capacitance partials; solve on wave 0 ----
+        double bb, bHb, alpha, hsdNorm;
         double Gc[M][NL][5];                          // per slot/loop: cR, sR, kx, ky, sign (0 = off)
-        double S6[NS][NS], mu[NS];
+        double mu[NS];
         {
             Se2Scratch<W, NL>& S = sh.scr[phase & 1];
-            publish_vec(bx, by, bth, S);
-            __syncthreads();
-            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-            if (wave > 0) { e0 = S.hi_vec[wave - 1][0]; e1 = S.hi_vec[wave - 1][1]; e2 = S.hi_vec[wave - 1][2]; }
-            double pbx[M], pby[M], pbth[M];
-            prev_vec(bx, by, bth, e0, e1, e2, pbx, pby, pbth);
-            constexpr int KR = 2 + NS + NS * (NS + 1) / 2;
-            double part[KR];
-#pragma unroll
-            for (int k = 0; k < KR; ++k) part[k] = 0.0;
+            publish_endpoint_vec(bx, by, bth, S);
+            // compact G_l,j = sigma [[Rg, kv],[0,1]]  (Rg rotation (cR,sR), kv = (kx,ky))
 #pragma unroll
             for (int s = 0; s < M; ++s) {
-#pragma unroll
-                for (int l = 0; l < NL; ++l) { Gc[s][l][0] = Gc[s][l][1] = Gc[s][l][2] = Gc[s][l][3] = Gc[s][l][4] = 0.0; }
-                if (!valid[s]) continue;
-                part[0] += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
-                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
-                double wx, wy, wth;
-                se2_apply_J(A[s], X[s], cz, sz, pbx[s], pby[s], pbth[s], bx[s], by[s], bth[s], wx, wy, wth);
-                part[1] += load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(wx, wy, wth);
-                // capacitance: G_l,j = sigma [[Rg, kv],[0,1]]
-                const Sym3 sg = load_sym3(P.chain, P.estride, F_SG, ek[s]);
-                double Gm[NL][3][3];
                 const int j = jbase + s * 64;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const LoopConst& q = sh.lc[l];
                     const LoopState& st = sh.ls[cur][l];
-                    const bool on = j > q.lo && j <= q.hi;
-                    const double sgn = on ? q.sigma : 0.0;
+                    const bool on = valid[s] && j > q.lo && j <= q.hi;
                     const double cf = st.pf[3], sf = st.pf[4];
                     const double cq = cf * cP[s] + sf * sP[s], sq = cf * sP[s] - sf * cP[s];
-                    const double cR = q.cz * cq + q.sz * sq, sR = q.cz * sq - q.sz * cq;
                     const double jx = -(st.pt[1] - X[s].y), jy = (st.pt[0] - X[s].x);
                     const double fx = cf * jx + sf * jy, fy = -sf * jx + cf * jy;
-                    const double kx = q.cz * fx + q.sz * fy, ky = -q.sz * fx + q.cz * fy;
-                    Gc[s][l][0] = cR; Gc[s][l][1] = sR; Gc[s][l][2] = kx; Gc[s][l][3] = ky; Gc[s][l][4] = sgn;
-                    Gm[l][0][0] = sgn * cR; Gm[l][0][1] = -sgn * sR; Gm[l][0][2] = sgn * kx;
-                    Gm[l][1][0] = sgn * sR; Gm[l][1][1] = sgn * cR;  Gm[l][1][2] = sgn * ky;
-                    Gm[l][2][0] = 0.0;      Gm[l][2][1] = 0.0;       Gm[l][2][2] = sgn;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        part[2 + l * 3 + r] += Gm[l][r][0] * ex[s] + Gm[l][r][1] * ey[s] + Gm[l][r][2] * eth[s];
+                    Gc[s][l][0] = q.cz * cq + q.sz * sq;
+                    Gc[s][l][1] = q.cz * sq - q.sz * cq;
+                    Gc[s][l][2] = q.cz * fx + q.sz * fy;
+                    Gc[s][l][3] = -q.sz * fx + q.cz * fy;
+                    Gc[s][l][4] = on ? q.sigma : 0.0;
                 }
-                double Hm[NL][3][3];
+            }
+            // row r (0..2) of G_l at slot s
+            auto grow = [&](int s, int l, int r, double& g0, double& g1, double& g2) {
+                const double sgn = Gc[s][l][4];
+                if (r == 0) { g0 = sgn * Gc[s][l][0]; g1 = -sgn * Gc[s][l][1]; g2 = sgn * Gc[s][l][2]; }
+                else if (r == 1) { g0 = sgn * Gc[s][l][1]; g1 = sgn * Gc[s][l][0]; g2 = sgn * Gc[s][l][3]; }
+                else { g0 = 0.0; g1 = 0.0; g2 = sgn; }
+            };
+            // group 1: b^T b, b^T H b, d (NS), S_11 (6)   -> red[wave][0..15]
+            {
+                double v[16];
 #pragma unroll
-                for (int l = 0; l < NL; ++l)
+                for (int k = 0; k < 16; ++k) v[k] = 0.0;
+                double cbx = pbx, cby = pby, cbth = pbth;  // b of pose j-1 (lane 0 carry)
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    const double qbx = lane_prev(bx[s], cbx), qby = lane_prev(by[s], cby), qbth = lane_prev(bth[s], cbth);
+                    if (s + 1 < M) { cbx = read_lane(bx[s], 63); cby = read_lane(by[s], 63); cbth = read_lane(bth[s], 63); }
+                    if (!valid[s]) continue;
+                    v[0] += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
+                    double wx, wy, wth;
+                    se2_apply_J(A[s], X[s], ldc(F_CZ, s), ldc(F_SZ, s), qbx, qby, qbth, bx[s], by[s], bth[s], wx, wy, wth);
+                    v[1] += ldsym(F_OM, s).quad(wx, wy, wth);
+                    const Sym3 sg = ldsym(F_SG, s);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            double g0, g1, g2;
+                            grow(s, l, r, g0, g1, g2);
+                            v[2 + 3 * l + r] += g0 * ex[s] + g1 * ey[s] + g2 * eth[s];
+                        }
+                    int idx = 2 + NS;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const double g0 = Gm[l][r][0], g1 = Gm[l][r][1], g2 = Gm[l][r][2];
-                        Hm[l][r][0] = g0 * sg.a00 + g1 * sg.a01 + g2 * sg.a02;
-                        Hm[l][r][1] = g0 * sg.a01 + g1 * sg.a11 + g2 * sg.a12;
-                        Hm[l][r][2] = g0 * sg.a02 + g1 * sg.a12 + g2 * sg.a22;
-                    }
-                int idx = 2 + NS;
+                        double g0, g1, g2, h0, h1, h2;
+                        grow(s, 0, r, g0, g1, g2);
+                        sg.mul(g0, g1, g2, h0, h1, h2);
 #pragma unroll
-                for (int r = 0; r < NS; ++r)
-#pragma unroll
-                    for (int c = r; c < NS; ++c) {
-                        const int l1 = r / 3, r1 = r % 3, l2 = c / 3, r2 = c % 3;
-                        part[idx] += Hm[l1][r1][0] * Gm[l2][r2][0] + Hm[l1][r1][1] * Gm[l2][r2][1] +
-                                     Hm[l1][r1][2] * Gm[l2][r2][2];
-                        ++idx;
+                        for (int c = r; c < 3; ++c) {
+                            double c0, c1, c2;
+                            grow(s, 0, c, c0, c1, c2);
+                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
+                        }
                     }
+                }
+                wave_sum16_store(v, &S.red[wave * 32]);
             }
-            if (tid < NL) part[1] += loop_quad(tid, S);
+            // group 2 (pair cells): S_12 (9), S_22 (6)     -> red[wave][16..31]
+            if constexpr (NL == 2) {
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = 0.0;
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    if (!valid[s]) continue;
+                    const Sym3 sg = ldsym(F_SG, s);
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {             // S_12[r][c], all 9
+                        double g0, g1, g2, h0, h1, h2;
+                        grow(s, 0, r, g0, g1, g2);
+                        sg.mul(g0, g1, g2, h0, h1, h2);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double c0, c1, c2;
+                            grow(s, 1, c, c0, c1, c2);
+                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {             // S_22 upper triangle
+                        double g0, g1, g2, h0, h1, h2;
+                        grow(s, 1, r, g0, g1, g2);
+                        sg.mul(g0, g1, g2, h0, h1, h2);
+#pragma unroll
+                        for (int c = r; c < 3; ++c) {
+                            double c0, c1, c2;
+                            grow(s, 1, c, c0, c1, c2);
+                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
+                        }
+                    }
+                }
+                wave_sum16_store(v, &S.red[wave * 32 + 16]);
+            }
+            __syncthreads();
             ++phase;
-            reduce(part, sh.scr[phase & 1]);
+            Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
+            if (wave == 0) {
+                // cross-wave totals: lane k sums value k over the waves, then broadcast
+                double acc = 0.0;
+                if (lane < 32) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) acc += S.red[w * 32 + lane];
+                }
+                // layout: [0] b^T b, [1] b^T H b, [2..2+NS) d, then S_11 (6); pair cells: [16..25) S_12,
+                // [25..31) S_22
+                auto T = [&](int k) { return read_lane(acc, k); };
+                double S6[NS][NS];
+                {
+                    int idx = 2 + NS;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = r; c < 3; ++c) { const double t = T(idx++); S6[r][c] = t; S6[c][r] = t; }
+                }
+                if constexpr (NL == 2) {
+                    int idx = 16;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { const double t = T(idx++); S6[r][3 + c] = t; S6[3 + c][r] = t; }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = r; c < 3; ++c) { const double t = T(idx++); S6[3 + r][3 + c] = t; S6[3 + c][3 + r] = t; }
+                }
+                double bHbTot = T(1);
+                const double bbTot = T(0);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const LoopConst& q = sh.lc[l];
+                    const LoopState& st = sh.ls[cur][l];
+                    S6[3 * l + 0][3 * l + 0] += q.sg[0]; S6[3 * l + 0][3 * l + 1] += q.sg[1]; S6[3 * l + 0][3 * l + 2] += q.sg[2];
+                    S6[3 * l + 1][3 * l + 0] += q.sg[1]; S6[3 * l + 1][3 * l + 1] += q.sg[3]; S6[3 * l + 1][3 * l + 2] += q.sg[4];
+                    S6[3 * l + 2][3 * l + 0] += q.sg[2]; S6[3 * l + 2][3 * l + 1] += q.sg[4]; S6[3 * l + 2][3 * l + 2] += q.sg[5];
+                    mu[3 * l + 0] = st.e[0] - T(2 + 3 * l + 0);
+                    mu[3 * l + 1] = st.e[1] - T(2 + 3 * l + 1);
+                    mu[3 * l + 2] = st.e[2] - T(2 + 3 * l + 2);
+                    bHbTot += loop_quad(l, S);
+                }
+                const bool ok = chol_solve<NS>(S6, mu);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) S2.sol[k] = mu[k];
+                    S2.sol[NS] = bbTot;
+                    S2.sol[NS + 1] = bHbTot;
+                    S2.sol[NS + 2] = ok ? 1.0 : 0.0;
+                }
+            }
+            __syncthreads();
             ++phase;
-            bb = part[0];
-            bHb = part[1];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) mu[k] = uni(S2.sol[k]);
+            bb = uni(S2.sol[NS]);
+            bHb = uni(S2.sol[NS + 1]);
+            if (uni(S2.sol[NS + 2]) == 0.0) { flags |= 2; break; }
             alpha = bb / bHb;
             hsdNorm = sqrt(alpha * alpha * bb);
-            int idx = 2 + NS;
-#pragma unroll
-            for (int r = 0; r < NS; ++r)
-#pragma unroll
-                for (int c = r; c < NS; ++c) { S6[r][c] = part[idx]; S6[c][r] = part[idx]; ++idx; }
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const LoopConst& q = sh.lc[l];
-                const LoopState& st = sh.ls[cur][l];
-                S6[3 * l + 0][3 * l + 0] += q.sg[0]; S6[3 * l + 0][3 * l + 1] += q.sg[1]; S6[3 * l + 0][3 * l + 2] += q.sg[2];
-                S6[3 * l + 1][3 * l + 0] += q.sg[1]; S6[3 * l + 1][3 * l + 1] += q.sg[3]; S6[3 * l + 1][3 * l + 2] += q.sg[4];
-                S6[3 * l + 2][3 * l + 0] += q.sg[2]; S6[3 * l + 2][3 * l + 1] += q.sg[4]; S6[3 * l + 2][3 * l + 2] += q.sg[5];
-                mu[3 * l + 0] = st.e[0] - part[2 + 3 * l + 0];
-                mu[3 * l + 1] = st.e[1] - part[2 + 3 * l + 1];
-                mu[3 * l + 2] = st.e[2] - part[2 + 3 * l + 2];
-            }
         }
-        if (!chol_solve<NS>(S6, mu)) { flags |= 2; break; }
 
-        // ---- phase I3: u, rho, prefix sums -> h_gn ----
+        // ---- phase C: u, rho, prefix sums -> h_gn; b^T h, h^T H h ----
+        double hgnNorm, bh, hHh;
         {
             double rx_[M], ry_[M], rth_[M];
 #pragma unroll
@@ -634,7 +780,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                     wth += sgn * (kx * m0 + ky * m1 + m2);
                 }
                 double vx, vy, vth;
-                load_sym3(P.chain, P.estride, F_SG, ek[s]).mul(wx, wy, wth, vx, vy, vth);
+                ldsym(F_SG, s).mul(wx, wy, wth, vx, vy, vth);
                 const double ux = -vx - ex[s], uy = -vy - ey[s], uth = -vth - eth[s];
                 rx_[s] = cP[s] * ux - sP[s] * uy;
                 ry_[s] = sP[s] * ux + cP[s] * uy;
@@ -666,7 +812,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             }
             Se2Scratch<W, NL>& S = sh.scr[phase & 1];
             // cross-wave correction: h_t(j) += base_t(w) + J (t_j - t_start(w)) * base_theta(w)
-            const double sx0 = read_lane(A[0].x, 0), sy0 = read_lane(A[0].y, 0);
+            const double sx0 = edge.x, sy0 = edge.y;
             double lastx = sx0, lasty = sy0;          // last valid pose of the wave
 #pragma unroll
             for (int s = 0; s < M; ++s) {
@@ -681,7 +827,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 S.scan[wave][3] = lastx - sx0; S.scan[wave][4] = lasty - sy0;
             }
             __syncthreads();
-            double bth_ = 0.0, bxx = 0.0, byy = 0.0;       // bases of this wave
+            double bth_ = 0.0, bxx = 0.0, byy = 0.0;       // bases of this wave = h of its predecessor
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 if (w < wave) {
@@ -690,21 +836,49 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                     bth_ += S.scan[w][0];
                 }
             }
+            bth_ = uni(bth_); bxx = uni(bxx); byy = uni(byy);
             ++phase;
-            double nrm[1] = {0.0};
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;          // |h|^2, b.h, h^T H h (odometry part)
+            double chx = bxx, chy = byy, chth = bth_;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
-                if (!valid[s]) { hx[s] = hy[s] = hth[s] = 0.0; continue; }
-                hth[s] = lth[s] + bth_;
-                hx[s] = lx_[s] + bxx - (X[s].y - sy0) * bth_;
-                hy[s] = ly_[s] + byy + (X[s].x - sx0) * bth_;
-                nrm[0] += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
+                if (valid[s]) {
+                    hth[s] = lth[s] + bth_;
+                    hx[s] = lx_[s] + bxx - (X[s].y - sy0) * bth_;
+                    hy[s] = ly_[s] + byy + (X[s].x - sx0) * bth_;
+                } else { hx[s] = hy[s] = hth[s] = 0.0; }
+                const double qhx = lane_prev(hx[s], chx), qhy = lane_prev(hy[s], chy), qhth = lane_prev(hth[s], chth);
+                if (s + 1 < M) { chx = read_lane(hx[s], 63); chy = read_lane(hy[s], 63); chth = read_lane(hth[s], 63); }
+                if (!valid[s]) continue;
+                p0 += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
+                p1 += bx[s] * hx[s] + by[s] * hy[s] + bth[s] * hth[s];
+                double wx, wy, wth;
+                se2_apply_J(A[s], X[s], ldc(F_CZ, s), ldc(F_SZ, s), qhx, qhy, qhth, hx[s], hy[s], hth[s], wx, wy, wth);
+                p2 += ldsym(F_OM, s).quad(wx, wy, wth);
             }
-            reduce(nrm, sh.scr[phase & 1]);
+            Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
+            publish_endpoint_vec(hx, hy, hth, S2);
+            p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+            if (lane == 0) { S2.red[wave] = p0; S2.red[16 + wave] = p1; S2.red[32 + wave] = p2; }
+            __syncthreads();
+            double tot[3];
+            gather_totals<3>(S2.red, W, tot);
+            hHh = tot[2];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) hHh += loop_quad(l, S2);
+            hHh = uni(hHh);
             ++phase;
-            hgnNorm = sqrt(nrm[0]);
+            hgnNorm = sqrt(tot[0]);
+            bh = tot[1];
         }
 
+#ifdef DBG_DUMP
+        if (it == 0) {
+            res.max_chi2 = hgnNorm; res.chi2_total = bb; res.iterations = (int)(bHb); res.tries = (int)(bh * 1e3);
+            res.flags = (int)(hHh * 1e3); res.evals = (int)(mu[0] * 1e6);
+            return;
+        }
+#endif
         // ---- trial loop ----
         bool goodStep = false;
         int numTries = 0;
@@ -716,85 +890,91 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
             else {
                 stepType = 2;
-                double part[2] = {0.0, 0.0};          // c = hsd.(hgn-hsd), |hgn-hsd|^2
+                double p0 = 0.0, p1 = 0.0;            // c = hsd.(hgn-hsd), |hgn-hsd|^2
 #pragma unroll
                 for (int s = 0; s < M; ++s) {
                     if (!valid[s]) continue;
                     const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
                     const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
-                    part[0] += sx * ax + sy * ay + sth * ath;
-                    part[1] += ax * ax + ay * ay + ath * ath;
+                    p0 += sx * ax + sy * ay + sth * ath;
+                    p1 += ax * ax + ay * ay + ath * ath;
                 }
-                reduce(part, sh.scr[phase & 1]);
+                p0 = wave_sum(p0); p1 = wave_sum(p1);
+                Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+                if (lane == 0) { S.red[wave] = p0; S.red[16 + wave] = p1; }
+                __syncthreads();
+                double tot[2];
+                gather_totals<2>(S.red, W, tot);
                 ++phase;
-                const double c = part[0], bma = part[1], hsdSq = alpha * alpha * bb;
+                const double c = tot[0], bma = tot[1], hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
                 else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
             }
-            // step, trial poses, publish
-            double dlx[M], dly[M], dlth[M];
+            // trial step h_dl = pcoef * b + qcoef * h_gn, and its linear gain from the
+            // per-iteration scalars
+            double pcoef, qcoef, hdlNorm;
+            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
+            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
+            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double bhdl = pcoef * bb + qcoef * bh;
+            double linearGain = -1 * hdlHhdl + 2 * bhdl;
             bool changed = false;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
-                if (stepType == 0) { dlx[s] = hx[s]; dly[s] = hy[s]; dlth[s] = hth[s]; }
+                if (!valid[s]) { Xn[s] = X[s]; continue; }
+                double dlx, dly, dlth;
+                if (stepType == 0) { dlx = hx[s]; dly = hy[s]; dlth = hth[s]; }
                 else if (stepType == 1) {
-                    dlx[s] = sdScale * (alpha * bx[s]); dly[s] = sdScale * (alpha * by[s]); dlth[s] = sdScale * (alpha * bth[s]);
+                    dlx = sdScale * (alpha * bx[s]); dly = sdScale * (alpha * by[s]); dlth = sdScale * (alpha * bth[s]);
                 } else {
                     const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
-                    dlx[s] = sx + beta * (hx[s] - sx); dly[s] = sy + beta * (hy[s] - sy); dlth[s] = sth + beta * (hth[s] - sth);
+                    dlx = sx + beta * (hx[s] - sx); dly = sy + beta * (hy[s] - sy); dlth = sth + beta * (hth[s] - sth);
                 }
-                if (!valid[s]) { dlx[s] = dly[s] = dlth[s] = 0.0; Xn[s] = X[s]; continue; }
-                Xn[s].x = X[s].x + dlx[s];
-                Xn[s].y = X[s].y + dly[s];
-                Xn[s].th = normalize_theta(X[s].th + dlth[s]);
-                sincos(Xn[s].th, &Xn[s].s, &Xn[s].c);
+                Xn[s].x = X[s].x + dlx;
+                Xn[s].y = X[s].y + dly;
+                Xn[s].th = normalize_theta(X[s].th + dlth);
+                sincos_pi(Xn[s].th, Xn[s].s, Xn[s].c);
                 changed |= (Xn[s].x != X[s].x) || (Xn[s].y != X[s].y) || (Xn[s].th != X[s].th);
             }
-            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
             const int trial = cur ^ 1;
-            publish_poses(Xn, S, trial);
-            publish_vec(dlx, dly, dlth, S);
-            __syncthreads();
-            // linear gain pieces + trial errors in one pass
-            double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // hdl^T H hdl, b.hdl, |hdl|^2, newChi, changed
-            {
-                Pose2 An[M];
-                prev_pose(Xn, edge_pose_of(S), An);
-                double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-                if (wave > 0) { e0 = S.hi_vec[wave - 1][0]; e1 = S.hi_vec[wave - 1][1]; e2 = S.hi_vec[wave - 1][2]; }
-                double pdx[M], pdy[M], pdth[M];
-                prev_vec(dlx, dly, dlth, e0, e1, e2, pdx, pdy, pdth);
-#pragma unroll
-                for (int s = 0; s < M; ++s) {
-                    if (!valid[s]) continue;
-                    const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
-                    const Sym3 om = load_sym3(P.chain, P.estride, F_OM, ek[s]);
-                    double wx, wy, wth;
-                    se2_apply_J(A[s], X[s], cz, sz, pdx[s], pdy[s], pdth[s], dlx[s], dly[s], dlth[s], wx, wy, wth);
-                    part[0] += om.quad(wx, wy, wth);
-                    part[1] += bx[s] * dlx[s] + by[s] * dly[s] + bth[s] * dlth[s];
-                    part[2] += dlx[s] * dlx[s] + dly[s] * dly[s] + dlth[s] * dlth[s];
-                    se2_error(An[s], Xn[s], ldc(F_TZX, s), ldc(F_TZY, s), cz, sz, ldc(F_THZ, s), enx[s], eny[s], enth[s]);
-                    part[3] += om.quad(enx[s], eny[s], enth[s]);
-                }
-                if (tid < NL) { part[0] += loop_quad(tid, S); part[3] += loop_eval(tid, trial); }
-                if (changed) part[4] = 1.0;
-            }
-            ++phase;
-            reduce(part, sh.scr[phase & 1]);
-            ++phase;
+            bool anyChanged;
+            const double newChi = evaluate(Xn, enx, eny, enth, trial, changed, anyChanged);
             ++evals;
-            double linearGain = -1 * part[0] + 2 * part[1];
-            const double hdlNorm = sqrt(part[2]);
-            const double newChi = part[3];
-            const bool anyChanged = part[4] != 0.0;
+#ifdef DBG_DUMP2
+            {
+                res.max_chi2 = newChi; res.chi2_total = currentChi; res.iterations = (int)(linearGain * 1e3); res.tries = stepType;
+                res.flags = (int)(Xn[0].th * 1e6); res.evals = (int)(Xn[0].c * 1e6);
+                return;
+            }
+#endif
             const double nonLinearGain = currentChi - newChi;
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
             const double rho = nonLinearGain / linearGain;
+#ifdef DBG_DUMP3
+            if (it == 0 && numTries == 1) { dbg0 = rho; dbg1 = newChi; dbg2 = currentChi; dbg3 = linearGain; }
+#endif
+#ifdef DBG_FLAGS
+            if (rho != rho) flags |= 4;
+            if (newChi != newChi) flags |= 8;
+            if (linearGain != linearGain) flags |= 16;
+            if (hHh != hHh) flags |= 32;
+            if (bh != bh) flags |= 64;
+            if (!(rho > 0)) flags |= 128;
+            if (newChi >= currentChi) flags |= 256;
+            if (!(linearGain > 0)) flags |= 512;
+#endif
+#ifdef DBG_SIDE
+            if (it == 0 && numTries == 1 && tid == 0) {
+                double* d = P.dbg + 8 * blockIdx.x;
+                d[0] = rho; d[1] = newChi; d[2] = currentChi; d[3] = linearGain; d[4] = hHh; d[5] = bh; d[6] = hgnNorm; d[7] = delta;
+            }
+#endif
             if (rho > 0) {                            // discardTop: commit the trial
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
+                edge = edgeN;
 #pragma unroll
                 for (int s = 0; s < M; ++s) { X[s] = Xn[s]; ex[s] = enx[s]; ey[s] = eny[s]; eth[s] = enth[s]; }
             }
@@ -820,7 +1000,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
     for (int s = 0; s < M; ++s) {
         if (!valid[s]) continue;
-        const double c = load_sym3(P.chain, P.estride, F_OM, ek[s]).quad(ex[s], ey[s], eth[s]);
+        const double c = ldsym(F_OM, s).quad(ex[s], ey[s], eth[s]);
         if (c != c) nan = true;
         else mx = fmax(mx, c);
     }
@@ -828,11 +1008,11 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     {
         Se2Scratch<W, NL>& S = sh.scr[phase & 1];
         const unsigned long long nb = __ballot(nan);
-        if (lane == 0) { S.red[wave][0] = mx; S.red[wave][1] = nb ? 1.0 : 0.0; }
+        if (lane == 0) { S.red[wave] = mx; S.red[16 + wave] = nb ? 1.0 : 0.0; }
         __syncthreads();
-        double m2 = S.red[0][0], nn = S.red[0][1];
+        double m2 = S.red[0], nn = S.red[16];
 #pragma unroll
-        for (int w = 1; w < W; ++w) { m2 = fmax(m2, S.red[w][0]); nn += S.red[w][1]; }
+        for (int w = 1; w < W; ++w) { m2 = fmax(m2, S.red[w]); nn += S.red[16 + w]; }
         mx = m2;
         nan = nn != 0.0;
         ++phase;
@@ -851,6 +1031,9 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     res.tries = tries_total;
     res.flags = flags;
     res.evals = evals;
+#ifdef DBG_DUMP3
+    res.max_chi2 = dbg0; res.chi2_total = dbg1; res.iterations = (int)(dbg2 * 1e3); res.tries = (int)(dbg3 * 1e3);
+#endif
 }
 
 }  // namespace ipc
