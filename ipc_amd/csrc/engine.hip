@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
+#include <utility>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -50,11 +52,17 @@ extern "C" const char* ipc_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------
 struct Variant { int W, M; };                   // waves per cell, poses per lane
 static const Variant kVariants[] = {
+    // M = 1
     {1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1}, {10, 1}, {12, 1}, {14, 1}, {16, 1},
-    {16, 2}, {16, 4}, {16, 8}, {16, 16},
+    // M = 2
+    {4, 2}, {5, 2}, {6, 2}, {7, 2}, {8, 2}, {10, 2}, {12, 2}, {16, 2},
+    // M = 3
+    {5, 3}, {6, 3}, {7, 3}, {8, 3},
+    // M = 4 and longer chains
+    {4, 4}, {6, 4}, {8, 4}, {16, 4}, {16, 8}, {16, 16},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kMaxBins = 20;
+constexpr int kMaxBins = 32;
 struct BinCaps { int n; int cap[kMaxBins]; };
 
 __device__ __forceinline__ int bin_of(const BinCaps& bc, int L)
@@ -210,9 +218,6 @@ static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& 
         hipLaunchKernelGGL((se2_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
         break;
     switch (variant) {
-#ifdef IPC_DEBUG_ONE_VARIANT
-        IPC_CASE(8, 10, 1)
-#else
         IPC_CASE(0, 1, 1)
         IPC_CASE(1, 2, 1)
         IPC_CASE(2, 3, 1)
@@ -225,11 +230,24 @@ static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& 
         IPC_CASE(9, 12, 1)
         IPC_CASE(10, 14, 1)
         IPC_CASE(11, 16, 1)
-        IPC_CASE(12, 16, 2)
-        IPC_CASE(13, 16, 4)
-        IPC_CASE(14, 16, 8)
-        IPC_CASE(15, 16, 16)
-#endif
+        IPC_CASE(12, 4, 2)
+        IPC_CASE(13, 5, 2)
+        IPC_CASE(14, 6, 2)
+        IPC_CASE(15, 7, 2)
+        IPC_CASE(16, 8, 2)
+        IPC_CASE(17, 10, 2)
+        IPC_CASE(18, 12, 2)
+        IPC_CASE(19, 16, 2)
+        IPC_CASE(20, 5, 3)
+        IPC_CASE(21, 6, 3)
+        IPC_CASE(22, 7, 3)
+        IPC_CASE(23, 8, 3)
+        IPC_CASE(24, 4, 4)
+        IPC_CASE(25, 6, 4)
+        IPC_CASE(26, 8, 4)
+        IPC_CASE(27, 16, 4)
+        IPC_CASE(28, 16, 8)
+        IPC_CASE(29, 16, 16)
         default: return hipErrorInvalidValue;
     }
 #undef IPC_CASE
@@ -330,9 +348,42 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // ------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------
+// Chain-length bins: each bin is served by one (W, M) kernel variant.  The policy string
+// (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens; a cell goes to
+// the listed variant of smallest capacity 64*W*M that holds it.
+struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
+static const char* kDefaultPolicy = "1x1,2x1,3x1,4x1,5x1,6x1,7x1,8x1,5x2,6x2,7x2,8x2,10x2,12x2,16x2,16x4,16x8,16x16";
+static bool make_plan(BinPlan& bp, std::string& err)
+{
+    const char* env = getenv("IPC_SE2_POLICY");
+    std::string pol = env && *env ? env : kDefaultPolicy;
+    std::vector<std::pair<int, int>> items;          // (cap, variant)
+    size_t pos = 0;
+    while (pos < pol.size()) {
+        size_t e = pol.find(',', pos);
+        if (e == std::string::npos) e = pol.size();
+        int w = 0, m = 0;
+        if (sscanf(pol.substr(pos, e - pos).c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
+        int v = -1;
+        for (int k = 0; k < kNumVariants; ++k) if (kVariants[k].W == w && kVariants[k].M == m) v = k;
+        if (v < 0) { err = "IPC_SE2_POLICY names a variant that is not compiled: " + pol.substr(pos, e - pos); return false; }
+        items.push_back({64 * w * m, v});
+        pos = e + 1;
+    }
+    std::sort(items.begin(), items.end());
+    if (items.empty() || (int)items.size() > kMaxBins) { err = "IPC_SE2_POLICY: 1..32 variants"; return false; }
+    bp.caps.n = (int)items.size();
+    for (int b = 0; b < kMaxBins; ++b) {
+        bp.caps.cap[b] = b < bp.caps.n ? items[b].first : 0;
+        bp.variant[b] = b < bp.caps.n ? items[b].second : -1;
+    }
+    return true;
+}
+
 struct ipc_engine {
     int dim = 2, V = 0, N = 0, device = 0;
     ipc_params_t prm{};
+    BinPlan plan{};
     hipStream_t own_stream = nullptr;
     // chain
     double* d_chain = nullptr; int estride = 0;
@@ -352,14 +403,6 @@ struct ipc_engine {
     unsigned long long *d_upper = nullptr, *d_bits = nullptr; unsigned char* d_acc = nullptr; size_t run_cap = 0;
 };
 
-static BinCaps make_caps()
-{
-    BinCaps bc;
-    bc.n = kNumVariants;
-    for (int b = 0; b < kMaxBins; ++b) bc.cap[b] = b < kNumVariants ? 64 * kVariants[b].W * kVariants[b].M : 0;
-    return bc;
-}
-
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
 extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, const double* odom_info,
@@ -377,6 +420,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipSetDevice(device));
     ipc_engine* h = new ipc_engine();
     h->dim = dim; h->V = n_vertices; h->prm = *params; h->device = device;
+    {
+        std::string perr;
+        if (!make_plan(h->plan, perr)) { delete h; return fail(IPC_ERR_ARG, "%s", perr.c_str()); }
+    }
     const int E = n_vertices - 1;
     h->estride = (E + 63) & ~63;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -437,7 +484,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
-    const int maxL = 64 * kVariants[kNumVariants - 1].W * kVariants[kNumVariants - 1].M;
+    const int maxL = h->plan.caps.cap[h->plan.caps.n - 1];
     for (int k = 0; k < n; ++k) {
         from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
         if (from[k] < 0 || to[k] < 0 || from[k] >= h->V || to[k] >= h->V)
@@ -521,7 +568,8 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
-    const BinCaps bc = make_caps();
+    const BinCaps bc = h->plan.caps;
+    const int nb = bc.n;
     constexpr int NS = 2 * (kMaxBins + 1);
     HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
     // pass 1: count
@@ -533,9 +581,9 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     unsigned counts[NS], offsets[NS];
     HIPCHK(hipMemcpyAsync(counts, h->d_counters, sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (counts[kNumVariants] || counts[(kMaxBins + 1) + kNumVariants])
-        return fail(IPC_ERR_LIMIT, "a sub-problem spans more than %d poses (largest kernel variant)",
-                    64 * kVariants[kNumVariants - 1].W * kVariants[kNumVariants - 1].M);
+    if (counts[nb] || counts[(kMaxBins + 1) + nb])
+        return fail(IPC_ERR_LIMIT, "a sub-problem spans more than %d poses (largest kernel variant in the policy)",
+                    bc.cap[nb - 1]);
     size_t total = 0;
     for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
     if (total > h->cells_cap) {
@@ -558,13 +606,14 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     const SolveParams sp{h->prm.fast_reject_iter_base, h->prm.slow_reject_iter_base};
     int launches = 0;
     HIPCHK(hipEventRecord(h->ev0, st));
-    for (int b = kNumVariants - 1; b >= 0; --b) {
+    for (int b = nb - 1; b >= 0; --b) {
         for (int nl = 2; nl >= 1; --nl) {
             const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
-            hipError_t e = nl == 1 ? launch_se2<1>(b, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
-                                   : launch_se2<2>(b, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+            const int var = h->plan.variant[b];
+            hipError_t e = nl == 1 ? launch_se2<1>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
+                                   : launch_se2<2>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }
