@@ -20,6 +20,7 @@
 
 #include "../../include/ipc_amd.h"
 #include "se2_cell.hpp"
+#include "se3_cell.hpp"
 
 using namespace ipc;
 
@@ -127,6 +128,74 @@ __global__ void k_se2_propagate(int V, const double* rec, int stride, double* po
         y += s * tx + c * ty;
         th = normalize_theta(th + rec[(size_t)F_THZ * stride + i - 1]);
         pose0[i] = x; pose0[(size_t)V + i] = y; pose0[2 * (size_t)V + i] = th;
+    }
+}
+
+// ---- SE3: EdgeSE3::read semantics (quaternion re-normalised), 6x6 information and its inverse ----
+__device__ void inv_sym6(const double* up, double* out)      // 21 upper -> 21 upper of the inverse
+{
+    double A[6][6], Li[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) { A[i][j] = up[sym6_idx(i, j)]; Li[i][j] = 0.0; }
+    // Cholesky A = L L^T (in the lower triangle of A)
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i][j];
+            for (int k = 0; k < j; ++k) sum -= A[i][k] * A[j][k];
+            A[i][j] = (j < i) ? sum / A[j][j] : sqrt(sum);
+        }
+    // Li = L^-1
+    for (int c = 0; c < 6; ++c)
+        for (int i = c; i < 6; ++i) {
+            double sum = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) sum -= A[i][k] * Li[k][c];
+            Li[i][c] = sum / A[i][i];
+        }
+    // inverse = Li^T Li
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+            double sum = 0.0;
+            for (int k = j; k < 6; ++k) sum += Li[k][i] * Li[k][j];
+            out[sym6_idx(i, j)] = sum;
+        }
+}
+
+__global__ void k_se3_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double* m = meas + 7 * (size_t)k;
+    const double qn = sqrt(m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + m[6] * m[6]);
+    double R[9];
+    R_from_quat(m[6] / qn, m[3] / qn, m[4] / qn, m[5] / qn, R);
+    for (int q = 0; q < 9; ++q) rec[(size_t)(G_RZ + q) * stride + k] = R[q];
+    for (int q = 0; q < 3; ++q) rec[(size_t)(G_TZ + q) * stride + k] = m[q];
+    double om[21], sg[21];
+    for (int q = 0; q < 21; ++q) om[q] = info[21 * (size_t)k + q] * scale;
+    inv_sym6(om, sg);
+    for (int q = 0; q < 21; ++q) {
+        rec[(size_t)(G_OM + q) * stride + k] = om[q];
+        rec[(size_t)(G_SG + q) * stride + k] = sg[q];
+    }
+}
+
+// propagateGuess for SE3: v0 = identity, v[i] = v[i-1] * z[i-1] (Isometry3 product)
+__global__ void k_se3_propagate(int V, const double* rec, int stride, double* pose0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    for (int q = 0; q < 9; ++q) pose0[(size_t)q * V] = R[q];
+    for (int q = 0; q < 3; ++q) pose0[(size_t)(9 + q) * V] = t[q];
+    for (int i = 1; i < V; ++i) {
+        double Rz[9], tz[3], Rn[9], d[3];
+        for (int q = 0; q < 9; ++q) Rz[q] = rec[(size_t)(G_RZ + q) * stride + i - 1];
+        for (int q = 0; q < 3; ++q) tz[q] = rec[(size_t)(G_TZ + q) * stride + i - 1];
+        m3_mul(R, Rz, Rn);
+        m3_vec(R, tz, d);
+        for (int q = 0; q < 3; ++q) t[q] += d[q];
+        for (int q = 0; q < 9; ++q) R[q] = Rn[q];
+        for (int q = 0; q < 9; ++q) pose0[(size_t)q * V + i] = R[q];
+        for (int q = 0; q < 3; ++q) pose0[(size_t)(9 + q) * V + i] = t[q];
     }
 }
 
@@ -254,6 +323,58 @@ static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& 
     return hipGetLastError();
 }
 
+// ---- SE3 cell kernel: same contract; variants kept few (the code is large) ----
+template <int W, int M, int NL>
+__global__ __launch_bounds__(64 * W) void se3_cells_kernel(Se3View P, const int2* cells, int ncells,
+                                                           SolveParams prm, CellOut out)
+{
+    __shared__ Se3Shared<W, M, NL> sh;
+    const int cell = blockIdx.x;
+    if (cell >= ncells) return;
+    const int2 cc = cells[cell];
+    int cand[2] = {cc.x, cc.y};
+    int lo = min(P.cand_from[cc.x], P.cand_to[cc.x]), hi = max(P.cand_from[cc.x], P.cand_to[cc.x]);
+    if (NL == 2) {
+        lo = min(lo, min(P.cand_from[cc.y], P.cand_to[cc.y]));
+        hi = max(hi, max(P.cand_from[cc.y], P.cand_to[cc.y]));
+    }
+    const int L = hi - lo;
+    const int base = NL == 1 ? prm.fast_iter : prm.slow_iter;
+    const int iterations = (L + NL > 100) ? base * 5 : base;       // consensus_utils.cpp:12-13
+    CellResult3 r;
+    se3_solve_cell<W, M, NL>(P, lo, L, cand, iterations, sh, r);
+    if (threadIdx.x == 0) {
+        out.max_chi2[cell] = r.max_chi2;
+        out.chi2_total[cell] = r.chi2_total;
+        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, r.evals);
+    }
+}
+
+static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4} };
+constexpr int kNumVariants3 = sizeof(kVariants3) / sizeof(kVariants3[0]);
+
+template <int NL>
+static hipError_t launch_se3(int variant, int n, hipStream_t st, const Se3View& P, const int2* cells,
+                             SolveParams prm, CellOut out)
+{
+#define IPC_CASE3(idx, WW, MM)                                                                    \
+    case idx:                                                                                     \
+        hipLaunchKernelGGL((se3_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
+        break;
+    switch (variant) {
+        IPC_CASE3(0, 1, 1)
+        IPC_CASE3(1, 2, 1)
+        IPC_CASE3(2, 4, 1)
+        IPC_CASE3(3, 8, 1)
+        IPC_CASE3(4, 16, 1)
+        IPC_CASE3(5, 16, 2)
+        IPC_CASE3(6, 16, 4)
+        default: return hipErrorInvalidValue;
+    }
+#undef IPC_CASE3
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // results -> bits
 // ------------------------------------------------------------------------------------------
@@ -353,10 +474,13 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // the listed variant of smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
 static const char* kDefaultPolicy = "1x1,2x1,3x1,4x1,5x1,6x1,7x1,8x1,5x2,6x2,7x2,8x2,10x2,12x2,16x2,16x4,16x8,16x16";
-static bool make_plan(BinPlan& bp, std::string& err)
+static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
+static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
-    const char* env = getenv("IPC_SE2_POLICY");
-    std::string pol = env && *env ? env : kDefaultPolicy;
+    const char* env = getenv(dim == 2 ? "IPC_SE2_POLICY" : "IPC_SE3_POLICY");
+    std::string pol = env && *env ? env : (dim == 2 ? kDefaultPolicy : kDefaultPolicy3);
+    const Variant* table = dim == 2 ? kVariants : kVariants3;
+    const int ntable = dim == 2 ? kNumVariants : kNumVariants3;
     std::vector<std::pair<int, int>> items;          // (cap, variant)
     size_t pos = 0;
     while (pos < pol.size()) {
@@ -365,8 +489,8 @@ static bool make_plan(BinPlan& bp, std::string& err)
         int w = 0, m = 0;
         if (sscanf(pol.substr(pos, e - pos).c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
         int v = -1;
-        for (int k = 0; k < kNumVariants; ++k) if (kVariants[k].W == w && kVariants[k].M == m) v = k;
-        if (v < 0) { err = "IPC_SE2_POLICY names a variant that is not compiled: " + pol.substr(pos, e - pos); return false; }
+        for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
+        if (v < 0) { err = "IPC_SE*_POLICY names a variant that is not compiled: " + pol.substr(pos, e - pos); return false; }
         items.push_back({64 * w * m, v});
         pos = e + 1;
     }
@@ -410,7 +534,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
 {
     if (!out) return fail(IPC_ERR_ARG, "ipc_create: out is NULL");
     *out = nullptr;
-    if (dim != 2) return fail(IPC_ERR_ARG, "ipc_create: dim=%d not supported by this build (SE2 only)", dim);
+    if (dim != 2 && dim != 3) return fail(IPC_ERR_ARG, "ipc_create: dim must be 2 (SE2) or 3 (SE3), got %d", dim);
     if (n_vertices < 2 || !odom_meas || !odom_info || !params)
         return fail(IPC_ERR_ARG, "ipc_create: need >= 2 vertices and non-NULL arrays");
     if (!(params->s_factor > 0)) return fail(IPC_ERR_ARG, "ipc_create: s_factor must be > 0");
@@ -422,27 +546,36 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     h->dim = dim; h->V = n_vertices; h->prm = *params; h->device = device;
     {
         std::string perr;
-        if (!make_plan(h->plan, perr)) { delete h; return fail(IPC_ERR_ARG, "%s", perr.c_str()); }
+        if (!make_plan(h->plan, dim, perr)) { delete h; return fail(IPC_ERR_ARG, "%s", perr.c_str()); }
     }
     const int E = n_vertices - 1;
+    const int ms = dim == 2 ? 3 : 7, is = dim == 2 ? 6 : 21, nf = dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
+    const int ps = dim == 2 ? 3 : 12;
     h->estride = (E + 63) & ~63;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * F_NFIELDS * h->estride));
-    HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * 3 * (size_t)n_vertices));
+    HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * nf * h->estride));
+    HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * ps * (size_t)n_vertices));
     HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1)));
     HIPCHK(hipMalloc(&h->d_offsets, sizeof(unsigned) * 2 * (kMaxBins + 1)));
     double *d_m = nullptr, *d_i = nullptr;
-    HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * E));
-    HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * E));
-    HIPCHK(hipMemcpy(d_m, odom_meas, sizeof(double) * 3 * E, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_i, odom_info, sizeof(double) * 6 * E, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * F_NFIELDS * h->estride, h->own_stream));
-    hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
-                       params->s_factor, h->d_chain, h->estride);
-    hipLaunchKernelGGL(k_se2_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
-                       h->d_pose0);
+    HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * E));
+    HIPCHK(hipMalloc(&d_i, sizeof(double) * is * E));
+    HIPCHK(hipMemcpy(d_m, odom_meas, sizeof(double) * ms * E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_i, odom_info, sizeof(double) * is * E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * nf * h->estride, h->own_stream));
+    if (dim == 2) {
+        hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
+                           params->s_factor, h->d_chain, h->estride);
+        hipLaunchKernelGGL(k_se2_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
+                           h->d_pose0);
+    } else {
+        hipLaunchKernelGGL(k_se3_prep, dim3((E + 63) / 64), dim3(64), 0, h->own_stream, E, d_m, d_i,
+                           params->s_factor, h->d_chain, h->estride);
+        hipLaunchKernelGGL(k_se3_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
+                           h->d_pose0);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->own_stream));
     HIPCHK(hipFree(d_m));
@@ -501,7 +634,8 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
     h->N = n;
     h->cstride = (n + 63) & ~63;
-    HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * F_NFIELDS * h->cstride));
+    const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21, nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
+    HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * nf * h->cstride));
     HIPCHK(hipMalloc(&h->d_from, sizeof(int) * n));
     HIPCHK(hipMalloc(&h->d_to, sizeof(int) * n));
     HIPCHK(hipMalloc(&h->d_lo, sizeof(int) * n));
@@ -513,13 +647,17 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     HIPCHK(hipMemcpy(h->d_hi, h->h_hi.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_order, h->order.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     double *d_m = nullptr, *d_i = nullptr;
-    HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * n));
-    HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * n));
-    HIPCHK(hipMemcpy(d_m, meas, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_i, info, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * F_NFIELDS * h->cstride, h->own_stream));
-    hipLaunchKernelGGL(k_se2_prep, dim3((n + 255) / 256), dim3(256), 0, h->own_stream, n, d_m, d_i, 1.0,
-                       h->d_cand, h->cstride);
+    HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * n));
+    HIPCHK(hipMalloc(&d_i, sizeof(double) * is * n));
+    HIPCHK(hipMemcpy(d_m, meas, sizeof(double) * ms * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_i, info, sizeof(double) * is * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * nf * h->cstride, h->own_stream));
+    if (h->dim == 2)
+        hipLaunchKernelGGL(k_se2_prep, dim3((n + 255) / 256), dim3(256), 0, h->own_stream, n, d_m, d_i, 1.0,
+                           h->d_cand, h->cstride);
+    else
+        hipLaunchKernelGGL(k_se3_prep, dim3((n + 63) / 64), dim3(64), 0, h->own_stream, n, d_m, d_i, 1.0,
+                           h->d_cand, h->cstride);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->own_stream));
     HIPCHK(hipFree(d_m));
@@ -538,10 +676,11 @@ extern "C" int ipc_initial_poses(ipc_engine_t* h, double* poses_out)
 {
     if (!h || !poses_out) return fail(IPC_ERR_ARG, "ipc_initial_poses: NULL argument");
     HIPCHK(hipSetDevice(h->device));
-    std::vector<double> tmp(3 * (size_t)h->V);
+    const int ps = h->dim == 2 ? 3 : 12;
+    std::vector<double> tmp(ps * (size_t)h->V);
     HIPCHK(hipMemcpy(tmp.data(), h->d_pose0, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < h->V; ++i)
-        for (int f = 0; f < 3; ++f) poses_out[3 * (size_t)i + f] = tmp[(size_t)f * h->V + i];
+        for (int f = 0; f < ps; ++f) poses_out[ps * (size_t)i + f] = tmp[(size_t)f * h->V + i];
     return IPC_OK;
 }
 
@@ -556,6 +695,14 @@ static Se2View make_view(const ipc_engine* h)
     if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
     P.dbg = dbgbuf;
 #endif
+    return P;
+}
+
+static Se3View make_view3(const ipc_engine* h)
+{
+    Se3View P;
+    P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
+    P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     return P;
 }
 
@@ -603,6 +750,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipGetLastError());
     // solve: longest chains first
     const Se2View P = make_view(h);
+    const Se3View P3 = make_view3(h);
     const SolveParams sp{h->prm.fast_reject_iter_base, h->prm.slow_reject_iter_base};
     int launches = 0;
     HIPCHK(hipEventRecord(h->ev0, st));
@@ -612,8 +760,13 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
             const int var = h->plan.variant[b];
-            hipError_t e = nl == 1 ? launch_se2<1>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
-                                   : launch_se2<2>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+            hipError_t e;
+            if (h->dim == 2)
+                e = nl == 1 ? launch_se2<1>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
+                            : launch_se2<2>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+            else
+                e = nl == 1 ? launch_se3<1>(var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out)
+                            : launch_se3<2>(var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }
