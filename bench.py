@@ -33,6 +33,11 @@ F_ITER = {1: 272.0, 2: 447.0}    # b, alpha, capacitance reduction, step, scans 
 F_EVAL = 80.0                    # sincos + residual + chi2 -- per error evaluation
 F_TRY = 70.0                     # step candidate, linear gain, update -- per evaluated trial
 B_ODOM = 72.0                    # bytes of one odometry record (3 + 6 doubles), SURVEY.md 8d
+# SE3 kernel (6x6 blocks): same structure, DESIGN.md
+F_ITER3 = {1: 3000.0, 2: 5200.0}
+F_EVAL3 = 270.0
+F_TRY3 = 150.0
+B_ODOM3 = 224.0                  # 7 + 21 doubles
 
 
 def build_workload(name):
@@ -50,6 +55,16 @@ def build_workload(name):
         g = synth.inject_outliers(synth.mit_like(), 5000, seed=5000)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=20)
         desc = "MIT-like SE2 synthetic (V=808, 20 true loops) + 5000 injected outliers"
+    elif name == "C4":
+        g = synth.inject_outliers(synth.sphere_like(), 2000, seed=2000)
+        cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=2450)
+        desc = "sphere2500-like SE3 synthetic (V=2500, 2450 true loops) + 2000 injected outliers"
+    elif name == "C4s":
+        g = synth.inject_outliers(synth.sphere_like(rings=20, per_ring=25, radius=20.0), 60, seed=60)
+        g2 = g.subset(np.concatenate([np.arange(0, 475, 8), np.arange(475, g.N)]))
+        g = g2
+        cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=60)
+        desc = "small sphere SE3 synthetic (V=500, 60 true loops) + 60 injected outliers"
     elif name == "tiny":
         g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)
@@ -150,14 +165,15 @@ def main():
     cells = eng.cell_info()                            # this rank's solved cells
     L = (cells["hi"] - cells["lo"]).astype(np.float64)
     nl = np.where(cells["i"] == cells["j"], 1, 2)
-    f_iter = np.where(nl == 1, F_ITER[1], F_ITER[2])
-    flops = float((L * (cells["iterations"] * f_iter + cells["evals"] * F_EVAL
-                        + np.maximum(cells["evals"] - 1, 0) * F_TRY)).sum())
-    alg_bytes = float((L * B_ODOM + nl * B_ODOM + 1.0 / 8).sum())
+    fi, fe, ft, bo = (F_ITER, F_EVAL, F_TRY, B_ODOM) if g.dim == 2 else (F_ITER3, F_EVAL3, F_TRY3, B_ODOM3)
+    f_iter = np.where(nl == 1, fi[1], fi[2])
+    flops = float((L * (cells["iterations"] * f_iter + cells["evals"] * fe
+                        + np.maximum(cells["evals"] - 1, 0) * ft)).sum())
+    alg_bytes = float((L * bo + nl * bo + 1.0 / 8).sum())
     achieved_tflops = flops / (sms * 1e-3) / 1e12
     roofline = {"bound": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": None,
-                "kernel": "se2_cells_kernel<T,M,NL> (%d launches per step, one per chain-length bin)" % launches,
+                "kernel": "se%d_cells_kernel<W,M,NL> (%d launches per step, one per chain-length bin)" % (g.dim, launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
