@@ -1,0 +1,276 @@
+#include "ipc_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace ipc_host {
+
+// ---------------------------------------------------------------------------------------
+// YAML subset: "key : value" per line, optional quotes, '#' comments (all the reference's cfg
+// files use, e.g. cfg/2D/INTEL_params.yaml)
+// ---------------------------------------------------------------------------------------
+static std::string trim(const std::string& s)
+{
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+
+static std::map<std::string, std::string> parse_yaml_subset(const std::string& path)
+{
+    std::ifstream in(path.c_str());
+    if (!in) throw std::runtime_error("readConfig: cannot open " + path);
+    std::map<std::string, std::string> kv;
+    std::string line;
+    while (std::getline(in, line)) {
+        bool inq = false;
+        size_t cut = std::string::npos;
+        for (size_t i = 0; i < line.size(); ++i) {
+            if (line[i] == '"') inq = !inq;
+            if (line[i] == '#' && !inq) { cut = i; break; }
+        }
+        if (cut != std::string::npos) line = line.substr(0, cut);
+        size_t c = line.find(':');
+        if (c == std::string::npos) continue;
+        std::string k = trim(line.substr(0, c)), v = trim(line.substr(c + 1));
+        if (v.size() >= 2 && ((v.front() == '"' && v.back() == '"') || (v.front() == '\'' && v.back() == '\'')))
+            v = v.substr(1, v.size() - 2);
+        if (!k.empty()) kv[k] = v;
+    }
+    return kv;
+}
+
+static const std::string& need(const std::map<std::string, std::string>& kv, const char* key)
+{
+    auto it = kv.find(key);
+    if (it == kv.end()) throw std::runtime_error(std::string("readConfig: missing key '") + key + "'");
+    return it->second;
+}
+static bool as_bool(const std::string& v)
+{
+    std::string l = v;
+    std::transform(l.begin(), l.end(), l.begin(), ::tolower);
+    if (l == "true" || l == "yes" || l == "on" || l == "1") return true;
+    if (l == "false" || l == "no" || l == "off" || l == "0") return false;
+    throw std::runtime_error("readConfig: not a boolean: " + v);
+}
+
+void readConfig(const std::string& cfg_filepath, Config& c)
+{
+    const auto kv = parse_yaml_subset(cfg_filepath);
+    c.name = need(kv, "name");
+    c.dataset = need(kv, "dataset");
+    c.ground_truth = need(kv, "ground_truth");
+    c.output = need(kv, "output");
+    c.s_factor = std::stod(need(kv, "s_factor"));
+    c.visualize = std::stoi(need(kv, "visualize")) == 1;
+    c.canonic_inliers = std::stoi(need(kv, "canonic_inliers"));
+    c.fast_reject_th = std::stod(need(kv, "fast_reject_th"));
+    c.fast_reject_iter_base = std::stoi(need(kv, "fast_reject_iter_base"));
+    c.slow_reject_th = std::stod(need(kv, "slow_reject_th"));
+    c.slow_reject_iter_base = std::stoi(need(kv, "slow_reject_iter_base"));
+    c.use_best_k_buddies = as_bool(need(kv, "use_best_k_buddies"));
+    c.k_buddies = std::stoi(need(kv, "k_buddies"));
+    c.use_recovery = as_bool(need(kv, "use_recovery"));
+}
+
+// ---------------------------------------------------------------------------------------
+void loadG2O(const std::string& path, PoseGraph& g)
+{
+    std::ifstream in(path.c_str());
+    if (!in) throw std::runtime_error("unable to open " + path);
+    g = PoseGraph();
+    std::map<int, std::vector<double>> verts;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream is(line);
+        std::string tag;
+        if (!(is >> tag)) continue;
+        int d = 0;
+        bool vertex = false;
+        if (tag == "VERTEX_SE2") { d = 2; vertex = true; }
+        else if (tag == "VERTEX_SE3:QUAT") { d = 3; vertex = true; }
+        else if (tag == "EDGE_SE2") d = 2;
+        else if (tag == "EDGE_SE3:QUAT") d = 3;
+        else continue;
+        if (g.dim == 0) g.dim = d;
+        if (g.dim != d) throw std::runtime_error("mixed 2D/3D records in " + path);
+        const int ms = d == 2 ? 3 : 7, is_ = d == 2 ? 6 : 21;
+        if (vertex) {
+            int id;
+            is >> id;
+            std::vector<double> v(ms);
+            for (double& x : v) is >> x;
+            if (!is) throw std::runtime_error("short vertex line: " + line);
+            verts[id] = v;
+        } else {
+            Edge e;
+            is >> e.from >> e.to;
+            e.meas.resize(ms);
+            e.info.resize(is_);
+            for (double& x : e.meas) is >> x;
+            for (double& x : e.info) is >> x;
+            if (!is) throw std::runtime_error("short edge line: " + line);
+            g.edges.push_back(e);
+        }
+    }
+    if (g.dim == 0) throw std::runtime_error("no SE2/SE3 records in " + path);
+    int expect = 0;
+    for (auto& kv : verts) {
+        if (kv.first != expect++) throw std::runtime_error("vertex ids are not exactly 0..V-1 in " + path);
+        g.vertices.push_back(kv.second);
+    }
+}
+
+void splitProblemConstraints(const PoseGraph& g, std::vector<Edge>& odom, std::vector<Edge>& loops)
+{
+    const int V = (int)g.vertices.size();
+    std::vector<const Edge*> byto(V, nullptr);
+    loops.clear();
+    for (const Edge& e : g.edges) {
+        if (e.from < 0 || e.to < 0 || e.from >= V || e.to >= V) throw std::runtime_error("edge joins an unknown vertex");
+        if (std::abs(e.to - e.from) > 1) loops.push_back(e);       // src/utils.cpp:184-186
+        else {
+            if (e.to != e.from + 1) throw std::runtime_error("odometry edge is not oriented i -> i+1");
+            if (byto[e.to]) throw std::runtime_error("duplicate odometry edge");
+            byto[e.to] = &e;
+        }
+    }
+    odom.clear();
+    for (int i = 1; i < V; ++i) {                                   // sorted by vertices()[1]->id (cmpEdgesID)
+        if (!byto[i]) throw std::runtime_error("odometry chain has a gap");
+        odom.push_back(*byto[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+static void check(int rc)
+{
+    if (rc != 0) throw std::runtime_error(std::string("ipc_amd: ") + ipc_last_error());
+}
+
+IPC::IPC(const PoseGraph& g, const std::vector<Edge>& odom, const Config& cfg, int device)
+{
+    _dim = g.dim;
+    _V = (int)g.vertices.size();
+    std::vector<double> meas, info;
+    for (const Edge& e : odom) {
+        meas.insert(meas.end(), e.meas.begin(), e.meas.end());
+        info.insert(info.end(), e.info.begin(), e.info.end());
+    }
+    ipc_params_t p{cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base,
+                   cfg.s_factor};
+    check(ipc_create(_dim, _V, meas.data(), info.data(), &p, device, &_h));
+}
+
+IPC::~IPC() { ipc_destroy(_h); }
+
+std::vector<uint8_t> IPC::agreementCheckAll(const std::vector<Edge>& cands)
+{
+    const int N = (int)cands.size();
+    std::vector<int> ids;
+    std::vector<double> meas, info;
+    for (const Edge& e : cands) {
+        ids.push_back(e.from);
+        ids.push_back(e.to);
+        meas.insert(meas.end(), e.meas.begin(), e.meas.end());
+        info.insert(info.end(), e.info.begin(), e.info.end());
+    }
+    check(ipc_set_candidates(_h, N, ids.data(), meas.data(), info.data()));
+    std::vector<uint8_t> acc(N, 0);
+    _order.assign(N, 0);
+    _max_consensus_set.clear();
+    if (N == 0) return acc;
+    check(ipc_run(_h, nullptr, acc.data()));
+    check(ipc_candidate_order(_h, _order.data()));
+    for (int k : _order)
+        if (acc[k]) _max_consensus_set.push_back(k);
+    return acc;
+}
+
+std::vector<double> IPC::initialPoses() const
+{
+    std::vector<double> out((size_t)_V * (_dim == 2 ? 3 : 12));
+    check(ipc_initial_poses(_h, out.data()));
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+static void write_pose(std::ofstream& out, int dim, const double* p)
+{
+    if (dim == 2) { out << p[0] << " " << p[1] << " " << p[2] << std::endl; return; }   // writeVertex, utils.cpp:239-245
+    // Quaterniond(R): same branches as Eigen (utils.cpp:248-258 writes t then qx qy qz qw)
+    const double* R = p;
+    double q[4], t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    out << p[9] << " " << p[10] << " " << p[11] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << std::endl;
+}
+
+SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph& g, const std::vector<Edge>& odom,
+                                             const std::vector<Edge>& loops, int device)
+{
+    SimulationResult r;
+    const int tot = (int)loops.size();
+    std::vector<char> is_inlier(tot, 0);
+    for (int i = 0; i < tot && i < cfg.canonic_inliers; ++i) is_inlier[i] = 1;    // simulation.cpp:24-25
+
+    IPC ipc(g, odom, cfg, device);
+    std::cout << "Starting simulation of incremental dataset -> Displaying relative status : " << std::endl;
+    std::cout << "S = " << cfg.s_factor << " | TH = " << cfg.fast_reject_th << std::endl;
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> bucket = ipc.agreementCheckAll(loops);
+    auto t1 = std::chrono::steady_clock::now();
+    r.total_time = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() / 1000000.0;
+    r.avg_time = tot ? r.total_time / tot : 0.0;
+    std::cout << "\nCompleted!" << std::endl;
+
+    for (int k = 0; k < tot; ++k) {                                               // simulation.cpp:70-81
+        if (is_inlier[k] && bucket[k]) ++r.tp;
+        else if (is_inlier[k] && !bucket[k]) ++r.fn;
+        else if (!is_inlier[k] && bucket[k]) ++r.fp;
+        else ++r.tn;
+    }
+    r.precision = r.tp / (float)(r.tp + r.fp);
+    r.recall = r.tp / (float)(r.tp + r.fn);
+    r.consensus_size = (int)ipc.getMaxConsensusSet().size();
+    std::cout << "Size of MAX consistent set = " << r.consensus_size << std::endl;
+    std::cout << "Avg Time x test = " << r.avg_time << " [s]\n";
+    std::cout << "Precision = " << r.precision << std::endl;
+    std::cout << "Recall = " << r.recall << std::endl;
+
+    // Trajectory file.  NOTE (not built yet): the reference writes the
+    // poses after a final optimize(1000) over odometry/s + accepted loops (simulation.cpp:50-65);
+    // this build writes the open-loop (propagateGuess) poses.
+    const std::vector<double> poses = ipc.initialPoses();
+    const int ps = g.dim == 2 ? 3 : 12;
+    std::ofstream outfile(cfg.output.c_str());
+    for (int i = 0; i < ipc.numVertices(); ++i) write_pose(outfile, g.dim, &poses[(size_t)i * ps]);
+    outfile.close();
+    const std::string out2 = cfg.output.substr(0, cfg.output.size() >= 3 ? cfg.output.size() - 3 : 0) + "PR";
+    outfile.open(out2.c_str());
+    outfile << r.precision << " " << r.recall << std::endl;
+    outfile << r.total_time << " " << r.avg_time << std::endl;
+    outfile.close();
+    return r;
+}
+
+}  // namespace ipc_host
