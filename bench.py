@@ -170,9 +170,27 @@ def main():
     flops = float((L * (cells["iterations"] * f_iter + cells["evals"] * fe
                         + np.maximum(cells["evals"] - 1, 0) * ft)).sum())
     alg_bytes = float((L * bo + nl * bo + 1.0 / 8).sum())
+    # HBM traffic of the solver kernels from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE / WRITE_SIZE in KB, separate passes; FETCH_SIZE doubled per the gfx950 note in
+    # MI355X_MICROARCH.md).  Per step, like `achieved`.
+    traffic = None
+    pmc_csv = os.path.join(ROOT, "profiles", "pmc_hbm_%s.csv" % args.workload)
+    if os.path.exists(pmc_csv) and world == 1:
+        import csv
+        f = w = 0.0
+        for r in csv.DictReader(open(pmc_csv)):
+            if "_cells_kernel" in r["kernel"]:
+                if r["counter"] == "FETCH_SIZE":
+                    f += float(r["sum_value"])
+                elif r["counter"] == "WRITE_SIZE":
+                    w += float(r["sum_value"])
+        traffic = (2.0 * f + w) * 1024.0
     achieved_tflops = flops / (sms * 1e-3) / 1e12
     roofline = {"bound": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
+                "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
+                                "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
+                                "L2-resident" % args.workload,
                 "kernel": "se%d_cells_kernel<W,M,NL> (%d launches per step, one per chain-length bin)" % (g.dim, launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
@@ -181,7 +199,7 @@ def main():
                         "the HBM roof is far away, see roofline_hbm"}
     hbm_gbs = alg_bytes / (sms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(hbm_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(hbm_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "algorithmic_bytes_per_step": alg_bytes}
 
     out = {

@@ -138,3 +138,73 @@ def test_full_size_c1_properties_and_sampled_parity(oracle):
     pick = rng.choice(len(cells), size=40, replace=False)
     worst = _compare_cells(O, g, cfg, eng, cells[pick])
     assert worst <= 1e-5
+
+
+def test_edge_cases_reversed_duplicate_and_full_span(oracle):
+    """Loop edges written high->low (the reference's graph_fixer exists because datasets contain
+    them), duplicated candidates, touching intervals, and a candidate spanning the whole chain."""
+    from ipc_amd import synth
+    from ipc_amd.graphio import PoseGraph
+    from ipc_amd.consensus import unpack_bits
+    O = oracle
+    g = synth.small_se2()
+    poses = O.propagate(2, g.odom_meas)
+    V = g.V
+
+    def rel(a, b, noise=0.0, seed=0):
+        r = O.pose_mul(2, O.pose_inv(2, poses[a]), poses[b])
+        rng = np.random.default_rng(seed)
+        return r + rng.normal(0, noise, 3)
+
+    ids = [(0, V - 1),          # whole chain, zero residual
+           (V - 1, 0),          # same, reversed orientation
+           (5, 20), (20, 5),    # a pair and its reverse (measurement inverted accordingly)
+           (5, 20),             # exact duplicate
+           (20, 33),            # touches [5,20] at one vertex: independent of it
+           (10, 12),            # shortest possible span
+           (40, 3)]             # reversed, noisy
+    meas = [rel(a, b) for a, b in ids]
+    meas[2] = rel(5, 20, 0.02, 1); meas[3] = rel(20, 5, 0.02, 2); meas[4] = meas[2].copy()
+    meas[7] = rel(40, 3, 0.3, 3)
+    info = np.tile(g.loop_info[0], (len(ids), 1))
+    gg = PoseGraph(2, g.vertices, g.odom_meas, g.odom_info, np.array(ids, dtype=np.int32), np.array(meas), info)
+    eng, cfg = _engine(gg)
+    bits, acc = eng.run()
+    ok, mx = _oracle_matrix(O, gg, cfg)
+    assert np.array_equal(unpack_bits(bits, eng.N), ok)
+    assert np.array_equal(acc, O.set_max(ok, O.candidate_order(gg.loop_ids)))
+    for c in eng.cell_info():
+        ref = mx[c["i"], c["j"]]
+        assert abs(ref - c["max_chi2"]) <= 1e-5 * max(abs(ref), 1e-9), (c, ref)
+    C = unpack_bits(bits, eng.N)
+    assert C[2, 5] == (C[2, 2] & C[5, 5])                   # touching intervals: AND of the diagonals
+    assert C[0, 0] == 1 and C[1, 1] == 1                    # zero-residual whole-chain loops agree
+
+
+def test_c_abi_argument_errors_on_gpu():
+    import ctypes as C
+    from ipc_amd import capi, synth
+    from ipc_amd.consensus import IPC, Config
+    lib = capi.load()
+    g = synth.small_se2()
+    eng = IPC(g, Config(), device=0)
+    ids = np.array([[3, 4]], dtype=np.int32)                # adjacent vertices = an odometry edge
+    z = np.zeros(3); inf = g.loop_info[0].copy()
+    rc = lib.ipc_set_candidates(eng.h, 1, ids.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                                inf.ctypes.data_as(C.c_void_p))
+    assert rc == -1 and b"adjacent" in lib.ipc_last_error()
+    ids = np.array([[3, g.V + 5]], dtype=np.int32)
+    rc = lib.ipc_set_candidates(eng.h, 1, ids.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                                inf.ctypes.data_as(C.c_void_p))
+    assert rc == -1 and b"outside" in lib.ipc_last_error()
+    # empty candidate list is legal; running it is a state error, not a crash
+    assert lib.ipc_set_candidates(eng.h, 0, None, None, None) == 0
+    assert lib.ipc_run(eng.h, None, None) == -3
+    # bad device / dim
+    h = C.c_void_p()
+    prm = capi.Params(6.251, 50, 11.345, 100, 10.0)
+    om, oi = np.ascontiguousarray(g.odom_meas), np.ascontiguousarray(g.odom_info)
+    assert lib.ipc_create(4, g.V, om.ctypes.data_as(C.c_void_p), oi.ctypes.data_as(C.c_void_p), C.byref(prm), 0,
+                          C.byref(h)) == -1
+    assert lib.ipc_create(2, g.V, om.ctypes.data_as(C.c_void_p), oi.ctypes.data_as(C.c_void_p), C.byref(prm), 99,
+                          C.byref(h)) == -1
