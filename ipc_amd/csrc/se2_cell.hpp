@@ -586,116 +586,70 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             }
         }
         // ---- phase B: b^T b, b^T H b, capacitance partials; solve on wave 0 ----
+        // G_{l,j} factors as Gamma_l * Phi_j with
+        //   Phi_j   = [[P_j, -kappa_j],[0,1]],  kappa_j = J (t_j - o)        (per edge, loop-free)
+        //   Gamma_l = sigma_l [[Lam_l, Lam_l K_l],[0,1]],  Lam_l = Rzl^T R_f^T,  K_l = J (t_to - o)
+        // (o = gauge position), so only Psi_j = Phi_j Cov_j Phi_j^T (6 values) and w_j = Phi_j e_j
+        // (3 values) are accumulated per loop range: S_ll' = Gamma_l M_ll' Gamma_l'^T with
+        // M_ll' = sum over range_l & range_l' of Psi_j, and d_l = e_l - Gamma_l W_l.
         double bb, bHb, alpha, hsdNorm;
-        double Gc[M][NL][5];                          // per slot/loop: cR, sR, kx, ky, sign (0 = off)
-        double mu[NS];
+        double nu[3], nu2[3];                         // Gamma_l^T mu_l  (loop 1, loop 2)
+        int lo1, hi1, lo2 = 0, hi2 = 0;
+        lo1 = sh.lc[0].lo; hi1 = sh.lc[0].hi;
+        if constexpr (NL == 2) { lo2 = sh.lc[1].lo; hi2 = sh.lc[1].hi; }
         {
             Se2Scratch<W, NL>& S = sh.scr[phase & 1];
             publish_endpoint_vec(bx, by, bth, S);
-            // compact G_l,j = sigma [[Rg, kv],[0,1]]  (Rg rotation (cR,sR), kv = (kx,ky))
+            // group 1: b^T b, b^T H b, W_1 (3), M_11 (6)            -> red[wave][0..10]
+            // group 2 (pair cells): W_2 (3), M_22 (6), M_12 (6)     -> red[wave][16..30]
+            double v1[16], v2[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { v1[k] = 0.0; v2[k] = 0.0; }
+            double cbx = pbx, cby = pby, cbth = pbth;  // b of pose j-1 (lane 0 carry)
 #pragma unroll
             for (int s = 0; s < M; ++s) {
+                const double qbx = lane_prev(bx[s], cbx), qby = lane_prev(by[s], cby), qbth = lane_prev(bth[s], cbth);
+                if (s + 1 < M) { cbx = read_lane(bx[s], 63); cby = read_lane(by[s], 63); cbth = read_lane(bth[s], 63); }
+                if (!valid[s]) continue;
+                v1[0] += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
+                double wx, wy, wth;
+                se2_apply_J(A[s], X[s], ldc(F_CZ, s), ldc(F_SZ, s), qbx, qby, qbth, bx[s], by[s], bth[s], wx, wy, wth);
+                v1[1] += ldsym(F_OM, s).quad(wx, wy, wth);
+                const Sym3 sg = ldsym(F_SG, s);
+                const double c = cP[s], sn = sP[s];
+                const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;     // kappa_j
+                // C = P Cov_tt P^T, c' = P (cov_02, cov_12)
+                const double cc = c * c, ss = sn * sn, cs = c * sn;
+                const double C00 = cc * sg.a00 - 2 * cs * sg.a01 + ss * sg.a11;
+                const double C01 = cs * (sg.a00 - sg.a11) + (cc - ss) * sg.a01;
+                const double C11 = ss * sg.a00 + 2 * cs * sg.a01 + cc * sg.a11;
+                const double c0 = c * sg.a02 - sn * sg.a12, c1 = sn * sg.a02 + c * sg.a12;
+                const double sth = sg.a22;
+                double psi[6];                       // 00 01 02 11 12 22
+                psi[2] = c0 - sth * kx;
+                psi[4] = c1 - sth * ky;
+                psi[0] = C00 - kx * c0 - kx * psi[2];          // C00 - 2 kx c0 + s kx^2
+                psi[1] = C01 - kx * c1 - ky * psi[2];          // C01 - kx c1 - ky c0 + s kx ky
+                psi[3] = C11 - ky * c1 - ky * psi[4];
+                psi[5] = sth;
+                const double w0 = c * ex[s] - sn * ey[s] - kx * eth[s];
+                const double w1 = sn * ex[s] + c * ey[s] - ky * eth[s];
+                const double w2 = eth[s];
                 const int j = jbase + s * 64;
+                const double m1 = (j > lo1 && j <= hi1) ? 1.0 : 0.0;
+                v1[2] += m1 * w0; v1[3] += m1 * w1; v1[4] += m1 * w2;
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const LoopConst& q = sh.lc[l];
-                    const LoopState& st = sh.ls[cur][l];
-                    const bool on = valid[s] && j > q.lo && j <= q.hi;
-                    const double cf = st.pf[3], sf = st.pf[4];
-                    const double cq = cf * cP[s] + sf * sP[s], sq = cf * sP[s] - sf * cP[s];
-                    const double jx = -(st.pt[1] - X[s].y), jy = (st.pt[0] - X[s].x);
-                    const double fx = cf * jx + sf * jy, fy = -sf * jx + cf * jy;
-                    Gc[s][l][0] = q.cz * cq + q.sz * sq;
-                    Gc[s][l][1] = q.cz * sq - q.sz * cq;
-                    Gc[s][l][2] = q.cz * fx + q.sz * fy;
-                    Gc[s][l][3] = -q.sz * fx + q.cz * fy;
-                    Gc[s][l][4] = on ? q.sigma : 0.0;
+                for (int k = 0; k < 6; ++k) v1[5 + k] += m1 * psi[k];
+                if constexpr (NL == 2) {
+                    const double m2 = (j > lo2 && j <= hi2) ? 1.0 : 0.0;
+                    const double m12 = m1 * m2;
+                    v2[0] += m2 * w0; v2[1] += m2 * w1; v2[2] += m2 * w2;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { v2[3 + k] += m2 * psi[k]; v2[9 + k] += m12 * psi[k]; }
                 }
             }
-            // row r (0..2) of G_l at slot s
-            auto grow = [&](int s, int l, int r, double& g0, double& g1, double& g2) {
-                const double sgn = Gc[s][l][4];
-                if (r == 0) { g0 = sgn * Gc[s][l][0]; g1 = -sgn * Gc[s][l][1]; g2 = sgn * Gc[s][l][2]; }
-                else if (r == 1) { g0 = sgn * Gc[s][l][1]; g1 = sgn * Gc[s][l][0]; g2 = sgn * Gc[s][l][3]; }
-                else { g0 = 0.0; g1 = 0.0; g2 = sgn; }
-            };
-            // group 1: b^T b, b^T H b, d (NS), S_11 (6)   -> red[wave][0..15]
-            {
-                double v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = 0.0;
-                double cbx = pbx, cby = pby, cbth = pbth;  // b of pose j-1 (lane 0 carry)
-#pragma unroll
-                for (int s = 0; s < M; ++s) {
-                    const double qbx = lane_prev(bx[s], cbx), qby = lane_prev(by[s], cby), qbth = lane_prev(bth[s], cbth);
-                    if (s + 1 < M) { cbx = read_lane(bx[s], 63); cby = read_lane(by[s], 63); cbth = read_lane(bth[s], 63); }
-                    if (!valid[s]) continue;
-                    v[0] += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
-                    double wx, wy, wth;
-                    se2_apply_J(A[s], X[s], ldc(F_CZ, s), ldc(F_SZ, s), qbx, qby, qbth, bx[s], by[s], bth[s], wx, wy, wth);
-                    v[1] += ldsym(F_OM, s).quad(wx, wy, wth);
-                    const Sym3 sg = ldsym(F_SG, s);
-#pragma unroll
-                    for (int l = 0; l < NL; ++l)
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            double g0, g1, g2;
-                            grow(s, l, r, g0, g1, g2);
-                            v[2 + 3 * l + r] += g0 * ex[s] + g1 * ey[s] + g2 * eth[s];
-                        }
-                    int idx = 2 + NS;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        double g0, g1, g2, h0, h1, h2;
-                        grow(s, 0, r, g0, g1, g2);
-                        sg.mul(g0, g1, g2, h0, h1, h2);
-#pragma unroll
-                        for (int c = r; c < 3; ++c) {
-                            double c0, c1, c2;
-                            grow(s, 0, c, c0, c1, c2);
-                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
-                        }
-                    }
-                }
-                wave_sum16_store(v, &S.red[wave * 32]);
-            }
-            // group 2 (pair cells): S_12 (9), S_22 (6)     -> red[wave][16..31]
-            if constexpr (NL == 2) {
-                double v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = 0.0;
-#pragma unroll
-                for (int s = 0; s < M; ++s) {
-                    if (!valid[s]) continue;
-                    const Sym3 sg = ldsym(F_SG, s);
-                    int idx = 0;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {             // S_12[r][c], all 9
-                        double g0, g1, g2, h0, h1, h2;
-                        grow(s, 0, r, g0, g1, g2);
-                        sg.mul(g0, g1, g2, h0, h1, h2);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            double c0, c1, c2;
-                            grow(s, 1, c, c0, c1, c2);
-                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {             // S_22 upper triangle
-                        double g0, g1, g2, h0, h1, h2;
-                        grow(s, 1, r, g0, g1, g2);
-                        sg.mul(g0, g1, g2, h0, h1, h2);
-#pragma unroll
-                        for (int c = r; c < 3; ++c) {
-                            double c0, c1, c2;
-                            grow(s, 1, c, c0, c1, c2);
-                            v[idx++] += h0 * c0 + h1 * c1 + h2 * c2;
-                        }
-                    }
-                }
-                wave_sum16_store(v, &S.red[wave * 32 + 16]);
-            }
+            wave_sum16_store(v1, &S.red[wave * 32]);
+            if constexpr (NL == 2) wave_sum16_store(v2, &S.red[wave * 32 + 16]);
             __syncthreads();
             ++phase;
             Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
@@ -706,30 +660,46 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
                     for (int w = 0; w < W; ++w) acc += S.red[w * 32 + lane];
                 }
-                // layout: [0] b^T b, [1] b^T H b, [2..2+NS) d, then S_11 (6); pair cells: [16..25) S_12,
-                // [25..31) S_22
                 auto T = [&](int k) { return read_lane(acc, k); };
-                double S6[NS][NS];
-                {
-                    int idx = 2 + NS;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = r; c < 3; ++c) { const double t = T(idx++); S6[r][c] = t; S6[c][r] = t; }
-                }
-                if constexpr (NL == 2) {
-                    int idx = 16;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { const double t = T(idx++); S6[r][3 + c] = t; S6[3 + c][r] = t; }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = r; c < 3; ++c) { const double t = T(idx++); S6[3 + r][3 + c] = t; S6[3 + c][3 + r] = t; }
-                }
+                double Gam[NL][3][3];
+                double S6[NS][NS], mu[NS];
                 double bHbTot = T(1);
                 const double bbTot = T(0);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const LoopConst& q = sh.lc[l];
+                    const LoopState& st = sh.ls[cur][l];
+                    // Lam = Rzl^T R_f^T = R(-(th_f + thz)):  [[a, b],[-b, a]]
+                    const double a = st.pf[3] * q.cz - st.pf[4] * q.sz, bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
+                    const double Kx = -(st.pt[1] - gauge.y), Ky = st.pt[0] - gauge.x;
+                    Gam[l][0][0] = q.sigma * a;   Gam[l][0][1] = q.sigma * bq; Gam[l][0][2] = q.sigma * (a * Kx + bq * Ky);
+                    Gam[l][1][0] = -q.sigma * bq; Gam[l][1][1] = q.sigma * a;  Gam[l][1][2] = q.sigma * (-bq * Kx + a * Ky);
+                    Gam[l][2][0] = 0.0;           Gam[l][2][1] = 0.0;          Gam[l][2][2] = q.sigma;
+                    bHbTot += loop_quad(l, S);
+                }
+                // S_ll' = Gam_l M_ll' Gam_l'^T  (+ Cov_l on the diagonal blocks)
+                auto block = [&](int l1, int l2, int base) {
+                    double Mm[3][3];
+                    Mm[0][0] = T(base + 0); Mm[0][1] = T(base + 1); Mm[0][2] = T(base + 2);
+                    Mm[1][0] = Mm[0][1];    Mm[1][1] = T(base + 3); Mm[1][2] = T(base + 4);
+                    Mm[2][0] = Mm[0][2];    Mm[2][1] = Mm[1][2];    Mm[2][2] = T(base + 5);
+                    double GM[3][3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            GM[r][c] = Gam[l1][r][0] * Mm[0][c] + Gam[l1][r][1] * Mm[1][c] + Gam[l1][r][2] * Mm[2][c];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const double t = GM[r][0] * Gam[l2][c][0] + GM[r][1] * Gam[l2][c][1] + GM[r][2] * Gam[l2][c][2];
+                            S6[3 * l1 + r][3 * l2 + c] = t;
+                            if (l1 != l2) S6[3 * l2 + c][3 * l1 + r] = t;
+                        }
+                };
+                block(0, 0, 5);
+                if constexpr (NL == 2) { block(1, 1, 16 + 3); block(0, 1, 16 + 9); }
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const LoopConst& q = sh.lc[l];
@@ -737,15 +707,20 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                     S6[3 * l + 0][3 * l + 0] += q.sg[0]; S6[3 * l + 0][3 * l + 1] += q.sg[1]; S6[3 * l + 0][3 * l + 2] += q.sg[2];
                     S6[3 * l + 1][3 * l + 0] += q.sg[1]; S6[3 * l + 1][3 * l + 1] += q.sg[3]; S6[3 * l + 1][3 * l + 2] += q.sg[4];
                     S6[3 * l + 2][3 * l + 0] += q.sg[2]; S6[3 * l + 2][3 * l + 1] += q.sg[4]; S6[3 * l + 2][3 * l + 2] += q.sg[5];
-                    mu[3 * l + 0] = st.e[0] - T(2 + 3 * l + 0);
-                    mu[3 * l + 1] = st.e[1] - T(2 + 3 * l + 1);
-                    mu[3 * l + 2] = st.e[2] - T(2 + 3 * l + 2);
-                    bHbTot += loop_quad(l, S);
+                    const int wb = l == 0 ? 2 : 16;
+                    const double W0 = T(wb), W1 = T(wb + 1), W2 = T(wb + 2);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        mu[3 * l + r] = st.e[r] - (Gam[l][r][0] * W0 + Gam[l][r][1] * W1 + Gam[l][r][2] * W2);
                 }
                 const bool ok = chol_solve<NS>(S6, mu);
                 if (lane == 0) {
+                    // publish nu_l = Gam_l^T mu_l
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) S2.sol[k] = mu[k];
+                    for (int l = 0; l < NL; ++l)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            S2.sol[3 * l + c] = Gam[l][0][c] * mu[3 * l] + Gam[l][1][c] * mu[3 * l + 1] + Gam[l][2][c] * mu[3 * l + 2];
                     S2.sol[NS] = bbTot;
                     S2.sol[NS + 1] = bHbTot;
                     S2.sol[NS + 2] = ok ? 1.0 : 0.0;
@@ -754,10 +729,10 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             __syncthreads();
             ++phase;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) mu[k] = uni(S2.sol[k]);
-            bb = uni(S2.sol[NS]);
-            bHb = uni(S2.sol[NS + 1]);
-            if (uni(S2.sol[NS + 2]) == 0.0) { flags |= 2; break; }
+            for (int k = 0; k < 3; ++k) { nu[k] = S2.sol[k]; nu2[k] = NL == 2 ? S2.sol[3 + k] : 0.0; }
+            bb = S2.sol[NS];
+            bHb = S2.sol[NS + 1];
+            if (S2.sol[NS + 2] == 0.0) { flags |= 2; break; }
             alpha = bb / bHb;
             hsdNorm = sqrt(alpha * alpha * bb);
         }
@@ -770,15 +745,17 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             for (int s = 0; s < M; ++s) {
                 rx_[s] = ry_[s] = rth_[s] = 0.0;
                 if (!valid[s]) continue;
-                double wx = 0.0, wy = 0.0, wth = 0.0;  // sum_l G^T mu
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const double cR = Gc[s][l][0], sR = Gc[s][l][1], kx = Gc[s][l][2], ky = Gc[s][l][3], sgn = Gc[s][l][4];
-                    const double m0 = mu[3 * l], m1 = mu[3 * l + 1], m2 = mu[3 * l + 2];
-                    wx += sgn * (cR * m0 + sR * m1);
-                    wy += sgn * (-sR * m0 + cR * m1);
-                    wth += sgn * (kx * m0 + ky * m1 + m2);
+                // sum_l G^T mu = Phi_j^T (sum_l mask_l nu_l),  Phi^T v = (P^T v_t, -kappa . v_t + v_th)
+                const int j = jbase + s * 64;
+                const double m1 = (j > lo1 && j <= hi1) ? 1.0 : 0.0;
+                double n0 = m1 * nu[0], n1 = m1 * nu[1], n2 = m1 * nu[2];
+                if constexpr (NL == 2) {
+                    const double m2 = (j > lo2 && j <= hi2) ? 1.0 : 0.0;
+                    n0 += m2 * nu2[0]; n1 += m2 * nu2[1]; n2 += m2 * nu2[2];
                 }
+                const double c = cP[s], sn = sP[s];
+                const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;
+                const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
                 double vx, vy, vth;
                 ldsym(F_SG, s).mul(wx, wy, wth, vx, vy, vth);
                 const double ux = -vx - ex[s], uy = -vy - ey[s], uth = -vth - eth[s];
