@@ -245,11 +245,22 @@ struct Se2Scratch {           // per-phase hand-off, double buffered
     double sol[NL * 3 + 3];   // capacitance solution mu, b^T b, b^T H b, ok flag (written by wave 0)
 };
 
+// Chain records of the cell are staged once into LDS (17 doubles per edge) when the variant's
+// capacity allows it (<= 1024 poses: 136 KB of the CU's 160 KB); every later use is then a
+// conflict-free ds_read_b64 instead of an L2 round trip in the middle of a latency-bound phase.
+template <int W, int M>
+struct Se2Cap {
+    static constexpr int CAP = 64 * W * M;
+    static constexpr bool STAGED = CAP <= 1024;
+    static constexpr int ROWS = STAGED ? CAP : 1;
+};
+
 template <int W, int M, int NL>
 struct Se2Shared {
     Se2Scratch<W, NL> scr[2];
     LoopConst lc[NL];
     LoopState ls[2][NL];      // [buffer][loop]; `cur` selects the committed one
+    double cst[F_NFIELDS][Se2Cap<W, M>::ROWS];
 };
 
 template <int W, int M, int NL>
@@ -343,11 +354,23 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     // (the per-field bases are recomputed from `fstride` with two SALU ops per use instead of
     // pinning 17 SGPR pairs: the kernel is SGPR-bound otherwise)
     unsigned fstride = (unsigned)P.estride << 3;      // bytes between two fields
-    auto opaque = [&]() {
+    constexpr bool STAGED = Se2Cap<W, M>::STAGED;
+    int jl[M];                                       // local edge index of the slot (0 when invalid)
 #pragma unroll
-        for (int s = 0; s < M; ++s) asm volatile("" : "+v"(eoff[s]));
+    for (int s = 0; s < M; ++s) jl[s] = valid[s] ? jbase + s * 64 - 1 : 0;
+    if constexpr (STAGED) {
+        for (int f = 0; f < F_NFIELDS; ++f)
+            for (int i = tid; i < L; i += 64 * W) sh.cst[f][i] = P.chain[(size_t)f * P.estride + lo_abs + i];
+        // visible after the next __syncthreads() (the first one of evaluate())
+    }
+    auto opaque = [&]() {
+        if constexpr (!STAGED) {
+#pragma unroll
+            for (int s = 0; s < M; ++s) asm volatile("" : "+v"(eoff[s]));
+        }
     };
     auto ldc = [&](int field, int s) -> double {
+        if constexpr (STAGED) return sh.cst[field][jl[s]];
         const char* fb = reinterpret_cast<const char*>(P.chain) + (size_t)field * fstride;
         return *reinterpret_cast<const double*>(fb + eoff[s]);
     };
@@ -509,8 +532,15 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     const int maxTrials = 100;
     int it_done = 0, tries_total = 0, flags = 0;
 
+#ifdef IPC_PHASE_TIMING
+    unsigned long long tmA = 0, tmB = 0, tmC = 0, tmT = 0, tm0 = __builtin_amdgcn_s_memtime();
+#define IPC_TICK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tm0; tm0 = t_; }
+#else
+#define IPC_TICK(acc)
+#endif
     for (int it = 0; it < iterations; ++it) {
         opaque();
+        IPC_TICK(tmT)
         // committed poses X (+ edge), errors e and loop state ls[cur] are consistent here
         Pose2 A[M];                                  // committed pose j-1 per slot
         prev_pose(X, edge, A);
@@ -585,6 +615,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
             }
         }
+        IPC_TICK(tmA)
         // ---- phase B: b^T b, b^T H b, capacitance partials; solve on wave 0 ----
         // G_{l,j} factors as Gamma_l * Phi_j with
         //   Phi_j   = [[P_j, -kappa_j],[0,1]],  kappa_j = J (t_j - o)        (per edge, loop-free)
@@ -737,6 +768,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             hsdNorm = sqrt(alpha * alpha * bb);
         }
 
+        IPC_TICK(tmB)
         // ---- phase C: u, rho, prefix sums -> h_gn; b^T h, h^T H h ----
         double hgnNorm, bh, hHh;
         {
@@ -856,6 +888,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             return;
         }
 #endif
+        IPC_TICK(tmC)
         // ---- trial loop ----
         bool goodStep = false;
         int numTries = 0;
@@ -971,6 +1004,17 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }
     }
 
+#ifdef IPC_PHASE_TIMING
+    IPC_TICK(tmT)
+    if (tid == 0 && P.dbg) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 0, tmA);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 1, tmB);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 2, tmC);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 3, tmT);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 4, (unsigned long long)it_done);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 5, (unsigned long long)evals);
+    }
+#endif
     // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
     double mx = 0.0;
     bool nan = false;
