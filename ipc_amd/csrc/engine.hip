@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens; a cell goes to
 // the listed variant of smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
-static const char* kDefaultPolicy = "1x1,2x1,3x1,4x1,5x1,6x1,7x1,8x1,5x2,6x2,7x2,8x2,10x2,12x2,16x2,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "1x1,2x1,3x1,4x1,5x1,6x1,7x1,8x1,5x2,6x2,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {

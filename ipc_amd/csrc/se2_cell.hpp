@@ -251,8 +251,11 @@ struct Se2Scratch {           // per-phase hand-off, double buffered
 template <int W, int M>
 struct Se2Cap {
     static constexpr int CAP = 64 * W * M;
-    static constexpr bool STAGED = CAP <= 1024;
-    static constexpr int ROWS = STAGED ? CAP : 1;
+    // all 17 fields up to 1024 poses; up to 1536 poses only the 11 fields of the residual pass
+    // (measurement + Omega), Sigma then stays an L2 read (used twice per outer iteration)
+    static constexpr int NSTAGED = CAP <= 1024 ? (int)F_NFIELDS : (CAP <= 1536 ? (int)F_SG : 0);
+    static constexpr int ROWS = NSTAGED > 0 ? CAP : 1;
+    static constexpr int FROWS = NSTAGED > 0 ? NSTAGED : 1;
 };
 
 template <int W, int M, int NL>
@@ -260,7 +263,7 @@ struct Se2Shared {
     Se2Scratch<W, NL> scr[2];
     LoopConst lc[NL];
     LoopState ls[2][NL];      // [buffer][loop]; `cur` selects the committed one
-    double cst[F_NFIELDS][Se2Cap<W, M>::ROWS];
+    double cst[Se2Cap<W, M>::FROWS][Se2Cap<W, M>::ROWS];
 };
 
 template <int W, int M, int NL>
@@ -354,23 +357,23 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     // (the per-field bases are recomputed from `fstride` with two SALU ops per use instead of
     // pinning 17 SGPR pairs: the kernel is SGPR-bound otherwise)
     unsigned fstride = (unsigned)P.estride << 3;      // bytes between two fields
-    constexpr bool STAGED = Se2Cap<W, M>::STAGED;
+    constexpr int NSTAGED = Se2Cap<W, M>::NSTAGED;
     int jl[M];                                       // local edge index of the slot (0 when invalid)
 #pragma unroll
     for (int s = 0; s < M; ++s) jl[s] = valid[s] ? jbase + s * 64 - 1 : 0;
-    if constexpr (STAGED) {
-        for (int f = 0; f < F_NFIELDS; ++f)
+    if constexpr (NSTAGED > 0) {
+        for (int f = 0; f < NSTAGED; ++f)
             for (int i = tid; i < L; i += 64 * W) sh.cst[f][i] = P.chain[(size_t)f * P.estride + lo_abs + i];
         // visible after the next __syncthreads() (the first one of evaluate())
     }
     auto opaque = [&]() {
-        if constexpr (!STAGED) {
+        if constexpr (NSTAGED < (int)F_NFIELDS) {
 #pragma unroll
             for (int s = 0; s < M; ++s) asm volatile("" : "+v"(eoff[s]));
         }
     };
     auto ldc = [&](int field, int s) -> double {
-        if constexpr (STAGED) return sh.cst[field][jl[s]];
+        if (field < NSTAGED) return sh.cst[field < NSTAGED ? field : 0][jl[s]];
         const char* fb = reinterpret_cast<const char*>(P.chain) + (size_t)field * fstride;
         return *reinterpret_cast<const double*>(fb + eoff[s]);
     };
