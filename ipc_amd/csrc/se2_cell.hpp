@@ -83,10 +83,6 @@ __device__ __forceinline__ double normalize_theta(double theta)
 // need elsewhere.
 __device__ __forceinline__ void sincos_pi(double th, double& sn, double& cs)
 {
-#ifdef DBG_OLD_SINCOS
-    sincos(th, &sn, &cs);
-    return;
-#endif
     const double n = rint(th * 6.36619772367581382433e-01);            // th * 2/pi
     double r = fma(-n, 1.57079632673412561417e+00, th);                // pio2_1 (33 bits)
     r = fma(-n, 6.07710050650619224932e-11, r);                        // pio2_1t
@@ -110,6 +106,14 @@ __device__ __forceinline__ void sincos_pi(double th, double& sn, double& cs)
     const double c0 = (q & 1) ? sr : cr;
     sn = (q & 2) ? -s0 : s0;
     cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// theta mod 2 pi into [-pi, pi] in three VALU ops (mul, rint, fma).  Equal to g2o's
+// normalize_theta except at the exact boundary value +pi (which g2o maps to -pi; same angle,
+// same chi2), valid for |theta| < ~1e15.
+__device__ __forceinline__ double wrap_pi(double theta)
+{
+    return fma(-6.283185307179586476925, rint(theta * 0.15915494309189533577), theta);
 }
 
 struct Sym3 {                 // symmetric 3x3: 00 01 02 11 12 22
@@ -153,7 +157,7 @@ __device__ __forceinline__ void se2_error(const Pose2& a, const Pose2& b, double
     const double lx = rx - tzx, ly = ry - tzy;
     ex = cz * lx + sz * ly;
     ey = -sz * lx + cz * ly;
-    eth = normalize_theta(normalize_theta(b.th - a.th) - thz);
+    eth = wrap_pi((b.th - a.th) - thz);
 }
 
 // w = J_edge applied to the pose perturbations (va at pose a, vb at pose b) of an edge a -> b
@@ -463,11 +467,20 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         double q0, q1, q2;
         om.mul(e0, e1, e2, q0, q1, q2);
         const double chi = e0 * q0 + e1 * q1 + e2 * q2;
-        const double cP = a.c * q.cz - a.s * q.sz, sP = a.s * q.cz + a.c * q.sz;
         st.e[0] = e0; st.e[1] = e1; st.e[2] = e2;
-        st.g[0] = cP * q0 - sP * q1; st.g[1] = sP * q0 + cP * q1; st.g[2] = q2;
         st.chi = chi;
         return chi;
+    };
+    // loop l: world-frame force g = (R_f Rz q_t, q_theta), q = Om e, of the committed state
+    // (only needed once per outer iteration, so it is kept out of the trial evaluations)
+    auto loop_force = [&](int l) {
+        const LoopConst& q = sh.lc[l];
+        LoopState& st = sh.ls[cur][l];
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        double q0, q1, q2;
+        om.mul(st.e[0], st.e[1], st.e[2], q0, q1, q2);
+        const double cP = st.pf[3] * q.cz - st.pf[4] * q.sz, sP = st.pf[4] * q.cz + st.pf[3] * q.sz;
+        st.g[0] = cP * q0 - sP * q1; st.g[1] = sP * q0 + cP * q1; st.g[2] = q2;
     };
     // loop l: w^T Om w with w = J_l applied to the end-point vectors in S.lvec (uniform data)
     auto loop_quad = [&](int l, const Se2Scratch<W, NL>& S) -> double {
@@ -487,11 +500,22 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     // lane flagged `changed`.  Two barriers.
     Pose2 edge = gauge;                              // committed pose of this wave's predecessor
     Pose2 edgeN = gauge;                             // same for the trial state
+#ifdef IPC_PHASE_TIMING
+    unsigned long long te[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+#define IPC_ETICK(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te[k] += t_ - tq; tq = t_; }
+#define IPC_ESTART() { tq = __builtin_amdgcn_s_memtime(); }
+#else
+#define IPC_ETICK(k)
+#define IPC_ESTART()
+#endif
     auto evaluate = [&](const Pose2 (&Y)[M], double (&ox)[M], double (&oy)[M], double (&oth)[M], int bsel,
                         bool changed, bool& anyChanged) -> double {
+        IPC_ESTART()
         Se2Scratch<W, NL>& S = sh.scr[phase & 1];
         publish_poses(Y, S, bsel);
+        IPC_ETICK(0)
         __syncthreads();
+        IPC_ETICK(1)
         edgeN = edge_pose_of(S);
         ++phase;
         Pose2 An[M];
@@ -504,16 +528,20 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                       ox[s], oy[s], oth[s]);
             part += ldsym(F_OM, s).quad(ox[s], oy[s], oth[s]);
         }
+        IPC_ETICK(2)
         if (tid < NL) part += loop_eval(tid, bsel);
         part = wave_sum(part);
         const bool wchg = __ballot(changed) != 0ull;
         Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
         if (lane == 0) { S2.red[wave] = part; S2.red[16 + wave] = wchg ? 1.0 : 0.0; }
+        IPC_ETICK(3)
         __syncthreads();
+        IPC_ETICK(4)
         double tot[2];
         gather_totals<2>(S2.red, W, tot);
         ++phase;
         anyChanged = tot[1] != 0.0;
+        IPC_ETICK(5)
         return tot[0];
     };
 
@@ -528,9 +556,6 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     }
 
     // ---------------- dog-leg (g2o OptimizationAlgorithmDogleg::solve) ----------------
-#ifdef DBG_DUMP3
-    double dbg0 = 0, dbg1 = 0, dbg2 = 0, dbg3 = 0;
-#endif
     double delta = 1e4;
     const int maxTrials = 100;
     int it_done = 0, tries_total = 0, flags = 0;
@@ -570,6 +595,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 mth[s] = gth[s] + (-dy * gx[s] + dx * gy[s]);
             }
             Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            if (tid < NL) loop_force(tid);            // read by the end-point owners after the barrier
             if (lane == 0) { S.lo_vec[wave][0] = mx[0]; S.lo_vec[wave][1] = my[0]; S.lo_vec[wave][2] = mth[0]; }
             if (lane == 63) { S.hi_vec[wave][0] = gx[M - 1]; S.hi_vec[wave][1] = gy[M - 1]; S.hi_vec[wave][2] = gth[M - 1]; }
             __syncthreads();
@@ -850,47 +876,31 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             }
             bth_ = uni(bth_); bxx = uni(bxx); byy = uni(byy);
             ++phase;
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0;          // |h|^2, b.h, h^T H h (odometry part)
-            double chx = bxx, chy = byy, chth = bth_;
+            // |h|^2 and b.h; h^T H h equals b^T h because h solves H h = b (the same identity that
+            // gives b^T H h = b^T b), so the second quadratic form is not evaluated.
+            double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
                 if (valid[s]) {
                     hth[s] = lth[s] + bth_;
                     hx[s] = lx_[s] + bxx - (X[s].y - sy0) * bth_;
                     hy[s] = ly_[s] + byy + (X[s].x - sx0) * bth_;
+                    p0 += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
+                    p1 += bx[s] * hx[s] + by[s] * hy[s] + bth[s] * hth[s];
                 } else { hx[s] = hy[s] = hth[s] = 0.0; }
-                const double qhx = lane_prev(hx[s], chx), qhy = lane_prev(hy[s], chy), qhth = lane_prev(hth[s], chth);
-                if (s + 1 < M) { chx = read_lane(hx[s], 63); chy = read_lane(hy[s], 63); chth = read_lane(hth[s], 63); }
-                if (!valid[s]) continue;
-                p0 += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
-                p1 += bx[s] * hx[s] + by[s] * hy[s] + bth[s] * hth[s];
-                double wx, wy, wth;
-                se2_apply_J(A[s], X[s], ldc(F_CZ, s), ldc(F_SZ, s), qhx, qhy, qhth, hx[s], hy[s], hth[s], wx, wy, wth);
-                p2 += ldsym(F_OM, s).quad(wx, wy, wth);
             }
             Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
-            publish_endpoint_vec(hx, hy, hth, S2);
-            p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-            if (lane == 0) { S2.red[wave] = p0; S2.red[16 + wave] = p1; S2.red[32 + wave] = p2; }
+            p0 = wave_sum(p0); p1 = wave_sum(p1);
+            if (lane == 0) { S2.red[wave] = p0; S2.red[16 + wave] = p1; }
             __syncthreads();
-            double tot[3];
-            gather_totals<3>(S2.red, W, tot);
-            hHh = tot[2];
-#pragma unroll
-            for (int l = 0; l < NL; ++l) hHh += loop_quad(l, S2);
-            hHh = uni(hHh);
+            double tot[2];
+            gather_totals<2>(S2.red, W, tot);
             ++phase;
             hgnNorm = sqrt(tot[0]);
             bh = tot[1];
+            hHh = bh;
         }
 
-#ifdef DBG_DUMP
-        if (it == 0) {
-            res.max_chi2 = hgnNorm; res.chi2_total = bb; res.iterations = (int)(bHb); res.tries = (int)(bh * 1e3);
-            res.flags = (int)(hHh * 1e3); res.evals = (int)(mu[0] * 1e6);
-            return;
-        }
-#endif
         IPC_TICK(tmC)
         // ---- trial loop ----
         bool goodStep = false;
@@ -946,7 +956,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
                 Xn[s].x = X[s].x + dlx;
                 Xn[s].y = X[s].y + dly;
-                Xn[s].th = normalize_theta(X[s].th + dlth);
+                Xn[s].th = wrap_pi(X[s].th + dlth);
                 sincos_pi(Xn[s].th, Xn[s].s, Xn[s].c);
                 changed |= (Xn[s].x != X[s].x) || (Xn[s].y != X[s].y) || (Xn[s].th != X[s].th);
             }
@@ -954,36 +964,14 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             bool anyChanged;
             const double newChi = evaluate(Xn, enx, eny, enth, trial, changed, anyChanged);
             ++evals;
-#ifdef DBG_DUMP2
-            {
-                res.max_chi2 = newChi; res.chi2_total = currentChi; res.iterations = (int)(linearGain * 1e3); res.tries = stepType;
-                res.flags = (int)(Xn[0].th * 1e6); res.evals = (int)(Xn[0].c * 1e6);
-                return;
-            }
-#endif
             const double nonLinearGain = currentChi - newChi;
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
-            const double rho = nonLinearGain / linearGain;
-#ifdef DBG_DUMP3
-            if (it == 0 && numTries == 1) { dbg0 = rho; dbg1 = newChi; dbg2 = currentChi; dbg3 = linearGain; }
-#endif
-#ifdef DBG_FLAGS
-            if (rho != rho) flags |= 4;
-            if (newChi != newChi) flags |= 8;
-            if (linearGain != linearGain) flags |= 16;
-            if (hHh != hHh) flags |= 32;
-            if (bh != bh) flags |= 64;
-            if (!(rho > 0)) flags |= 128;
-            if (newChi >= currentChi) flags |= 256;
-            if (!(linearGain > 0)) flags |= 512;
-#endif
-#ifdef DBG_SIDE
-            if (it == 0 && numTries == 1 && tid == 0) {
-                double* d = P.dbg + 8 * blockIdx.x;
-                d[0] = rho; d[1] = newChi; d[2] = currentChi; d[3] = linearGain; d[4] = hHh; d[5] = bh; d[6] = hgnNorm; d[7] = delta;
-            }
-#endif
-            if (rho > 0) {                            // discardTop: commit the trial
+            // rho = nonLinearGain / linearGain is only ever compared with 0, 0.25 and 0.75, so the
+            // comparisons are done without the FP64 division (NaN still fails every test)
+            const bool linPos = linearGain > 0;
+            auto rho_gt = [&](double t) { return linPos ? nonLinearGain > t * linearGain : nonLinearGain < t * linearGain; };
+            auto rho_lt = [&](double t) { return linPos ? nonLinearGain < t * linearGain : nonLinearGain > t * linearGain; };
+            if (rho_gt(0.0)) {                        // rho > 0, discardTop: commit the trial
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
@@ -991,8 +979,8 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
                 for (int s = 0; s < M; ++s) { X[s] = Xn[s]; ex[s] = enx[s]; ey[s] = eny[s]; eth[s] = enth[s]; }
             }
-            if (rho > 0.75) delta = fmax(delta, 3 * hdlNorm);
-            else if (rho < 0.25) delta *= 0.5;
+            if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
+            else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
                 if (stepType == 0) {
                     // identical GN trial repeats while hgnNorm < delta: each halves delta
@@ -1016,7 +1004,10 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 3, tmT);
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 4, (unsigned long long)it_done);
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 5, (unsigned long long)evals);
+        for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 8 + k, te[k]);
     }
+    if (tid == 64 * (W - 1) && P.dbg)
+        for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 16 + k, te[k]);
 #endif
     // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
     double mx = 0.0;
@@ -1055,9 +1046,6 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     res.tries = tries_total;
     res.flags = flags;
     res.evals = evals;
-#ifdef DBG_DUMP3
-    res.max_chi2 = dbg0; res.chi2_total = dbg1; res.iterations = (int)(dbg2 * 1e3); res.tries = (int)(dbg3 * 1e3);
-#endif
 }
 
 }  // namespace ipc
