@@ -116,6 +116,17 @@ __device__ __forceinline__ double wrap_pi(double theta)
     return fma(-6.283185307179586476925, rint(theta * 0.15915494309189533577), theta);
 }
 
+// (cos, sin) of theta + d from (c, s) of theta for |d| < 2^-6: Taylor kernels to d^7 / d^8
+// (truncation < 2e-22), applied as c' = c + (c (cos d - 1) - s sin d) so no 1 + tiny rounding.
+__device__ __forceinline__ void rotate_small(double c, double s, double d, double& cn, double& sn)
+{
+    const double z = d * d;
+    const double sd = d * fma(z, fma(z, fma(z, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double cm = z * fma(z, fma(z, fma(z, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5);
+    cn = fma(-s, sd, fma(c, cm, c));
+    sn = fma(c, sd, fma(s, cm, s));
+}
+
 struct Sym3 {                 // symmetric 3x3: 00 01 02 11 12 22
     double a00, a01, a02, a11, a12, a22;
     __device__ __forceinline__ void mul(double x, double y, double z, double& ox, double& oy, double& oz) const
@@ -942,24 +953,33 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
             const double bhdl = pcoef * bb + qcoef * bh;
             double linearGain = -1 * hdlHhdl + 2 * bhdl;
-            bool changed = false;
+            // h_dl = pcoef * b + qcoef * h_gn for every step type
+            bool changed = false, big = false;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
-                if (!valid[s]) { Xn[s] = X[s]; continue; }
-                double dlx, dly, dlth;
-                if (stepType == 0) { dlx = hx[s]; dly = hy[s]; dlth = hth[s]; }
-                else if (stepType == 1) {
-                    dlx = sdScale * (alpha * bx[s]); dly = sdScale * (alpha * by[s]); dlth = sdScale * (alpha * bth[s]);
-                } else {
-                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
-                    dlx = sx + beta * (hx[s] - sx); dly = sy + beta * (hy[s] - sy); dlth = sth + beta * (hth[s] - sth);
-                }
-                Xn[s].x = X[s].x + dlx;
-                Xn[s].y = X[s].y + dly;
-                Xn[s].th = wrap_pi(X[s].th + dlth);
-                sincos_pi(Xn[s].th, Xn[s].s, Xn[s].c);
-                changed |= (Xn[s].x != X[s].x) || (Xn[s].y != X[s].y) || (Xn[s].th != X[s].th);
+                Xn[s] = X[s];
+                if (!valid[s]) continue;
+                Xn[s].x = X[s].x + fma(pcoef, bx[s], qcoef * hx[s]);
+                Xn[s].y = X[s].y + fma(pcoef, by[s], qcoef * hy[s]);
+                Xn[s].th = wrap_pi(X[s].th + fma(pcoef, bth[s], qcoef * hth[s]));
+                big |= fabs(Xn[s].th - X[s].th) >= 0.015625;
             }
+            // cos/sin of the trial angles: rotate the committed (c, s) by the (tiny) effective change
+            // unless some lane of the wave moved by >= 2^-6 rad (then the full kernel, whole wave)
+            if (__ballot(big) != 0ull) {
+#pragma unroll
+                for (int s = 0; s < M; ++s)
+                    if (valid[s]) sincos_pi(Xn[s].th, Xn[s].s, Xn[s].c);
+            } else {
+#pragma unroll
+                for (int s = 0; s < M; ++s)
+                    if (valid[s]) rotate_small(X[s].c, X[s].s, Xn[s].th - X[s].th, Xn[s].c, Xn[s].s);
+            }
+            if (stepType == 1) {                      // only the steepest-descent no-op shortcut needs it
+#pragma unroll
+                for (int s = 0; s < M; ++s)
+                    changed |= valid[s] && ((Xn[s].x != X[s].x) || (Xn[s].y != X[s].y) || (Xn[s].th != X[s].th));
+            } else changed = true;
             const int trial = cur ^ 1;
             bool anyChanged;
             const double newChi = evaluate(Xn, enx, eny, enth, trial, changed, anyChanged);
