@@ -257,7 +257,7 @@ struct Se2Scratch {           // per-phase hand-off, double buffered
     double lo_vec[W][3];      // vector held by lane 0 / slot 0
     double lvec[NL][2][3];    // vectors at the loop end points (from, to)
     double scan[W][5];        // per-wave scan totals
-    double sol[NL * 3 + 3];   // capacitance solution mu, b^T b, b^T H b, ok flag (written by wave 0)
+    double sol[NL * 3 + 3];   // nu = Gamma^T mu per loop, b^T b, b^T H b, ok flag (written by wave 0)
 };
 
 // Chain records of the cell are staged once into LDS (17 doubles per edge) when the variant's
@@ -279,6 +279,7 @@ struct Se2Shared {
     LoopConst lc[NL];
     LoopState ls[2][NL];      // [buffer][loop]; `cur` selects the committed one
     double cst[Se2Cap<W, M>::FROWS][Se2Cap<W, M>::ROWS];
+    double wtmp[W][64];       // wave-private temporaries of the lane-parallel capacitance solve
 };
 
 template <int W, int M, int NL>
@@ -725,77 +726,88 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             ++phase;
             Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
             if (wave == 0) {
-                // cross-wave totals: lane k sums value k over the waves, then broadcast
+            // ---- capacitance solve, lane-parallel on wave 0:
+            //   lane t < 32      : total of partial t over the waves          -> wtmp[t]
+            //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> wtmp[32 + .]
+            //   lane r*(NS+1)+c  : S[r][c] (c < NS) / rhs d[r] (c == NS), then Gauss-Jordan in place
+            double* wt = sh.wtmp[wave];
+            {
                 double acc = 0.0;
                 if (lane < 32) {
 #pragma unroll
                     for (int w = 0; w < W; ++w) acc += S.red[w * 32 + lane];
+                    wt[lane] = acc;
                 }
-                auto T = [&](int k) { return read_lane(acc, k); };
-                double Gam[NL][3][3];
-                double S6[NS][NS], mu[NS];
-                double bHbTot = T(1);
-                const double bbTot = T(0);
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
+                if (lane < NL * 9) {
+                    const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
                     const LoopConst& q = sh.lc[l];
                     const LoopState& st = sh.ls[cur][l];
-                    // Lam = Rzl^T R_f^T = R(-(th_f + thz)):  [[a, b],[-b, a]]
-                    const double a = st.pf[3] * q.cz - st.pf[4] * q.sz, bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
+                    const double Aq = st.pf[3] * q.cz - st.pf[4] * q.sz, Bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
                     const double Kx = -(st.pt[1] - gauge.y), Ky = st.pt[0] - gauge.x;
-                    Gam[l][0][0] = q.sigma * a;   Gam[l][0][1] = q.sigma * bq; Gam[l][0][2] = q.sigma * (a * Kx + bq * Ky);
-                    Gam[l][1][0] = -q.sigma * bq; Gam[l][1][1] = q.sigma * a;  Gam[l][1][2] = q.sigma * (-bq * Kx + a * Ky);
-                    Gam[l][2][0] = 0.0;           Gam[l][2][1] = 0.0;          Gam[l][2][2] = q.sigma;
-                    bHbTot += loop_quad(l, S);
+                    double g;
+                    if (i == 0) g = a == 0 ? Aq : (a == 1 ? Bq : Aq * Kx + Bq * Ky);
+                    else if (i == 1) g = a == 0 ? -Bq : (a == 1 ? Aq : -Bq * Kx + Aq * Ky);
+                    else g = a == 2 ? 1.0 : 0.0;
+                    wt[32 + lane] = q.sigma * g;
                 }
-                // S_ll' = Gam_l M_ll' Gam_l'^T  (+ Cov_l on the diagonal blocks)
-                auto block = [&](int l1, int l2, int base) {
-                    double Mm[3][3];
-                    Mm[0][0] = T(base + 0); Mm[0][1] = T(base + 1); Mm[0][2] = T(base + 2);
-                    Mm[1][0] = Mm[0][1];    Mm[1][1] = T(base + 3); Mm[1][2] = T(base + 4);
-                    Mm[2][0] = Mm[0][2];    Mm[2][1] = Mm[1][2];    Mm[2][2] = T(base + 5);
-                    double GM[3][3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            GM[r][c] = Gam[l1][r][0] * Mm[0][c] + Gam[l1][r][1] * Mm[1][c] + Gam[l1][r][2] * Mm[2][c];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const double t = GM[r][0] * Gam[l2][c][0] + GM[r][1] * Gam[l2][c][1] + GM[r][2] * Gam[l2][c][2];
-                            S6[3 * l1 + r][3 * l2 + c] = t;
-                            if (l1 != l2) S6[3 * l2 + c][3 * l1 + r] = t;
-                        }
-                };
-                block(0, 0, 5);
-                if constexpr (NL == 2) { block(1, 1, 16 + 3); block(0, 1, 16 + 9); }
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const LoopConst& q = sh.lc[l];
-                    const LoopState& st = sh.ls[cur][l];
-                    S6[3 * l + 0][3 * l + 0] += q.sg[0]; S6[3 * l + 0][3 * l + 1] += q.sg[1]; S6[3 * l + 0][3 * l + 2] += q.sg[2];
-                    S6[3 * l + 1][3 * l + 0] += q.sg[1]; S6[3 * l + 1][3 * l + 1] += q.sg[3]; S6[3 * l + 1][3 * l + 2] += q.sg[4];
-                    S6[3 * l + 2][3 * l + 0] += q.sg[2]; S6[3 * l + 2][3 * l + 1] += q.sg[4]; S6[3 * l + 2][3 * l + 2] += q.sg[5];
-                    const int wb = l == 0 ? 2 : 16;
-                    const double W0 = T(wb), W1 = T(wb + 1), W2 = T(wb + 2);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        mu[3 * l + r] = st.e[r] - (Gam[l][r][0] * W0 + Gam[l][r][1] * W1 + Gam[l][r][2] * W2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int RS = NS + 1;                    // row stride of the augmented system
+            double val = 0.0;
+            const int r = lane / RS, c = lane % RS;
+            if (lane < NS * RS) {
+                const int l1 = r / 3, i = r % 3;
+                const double g10 = wt[32 + l1 * 9 + i * 3], g11 = wt[32 + l1 * 9 + i * 3 + 1], g12 = wt[32 + l1 * 9 + i * 3 + 2];
+                if (c < NS) {
+                    const int l2 = c / 3, k = c % 3;
+                    const int mb = l1 == l2 ? (l1 == 0 ? 5 : 19) : 25;
+                    const double m00 = wt[mb], m01 = wt[mb + 1], m02 = wt[mb + 2], m11 = wt[mb + 3], m12 = wt[mb + 4], m22 = wt[mb + 5];
+                    const double t0 = g10 * m00 + g11 * m01 + g12 * m02;
+                    const double t1 = g10 * m01 + g11 * m11 + g12 * m12;
+                    const double t2 = g10 * m02 + g11 * m12 + g12 * m22;
+                    val = t0 * wt[32 + l2 * 9 + k * 3] + t1 * wt[32 + l2 * 9 + k * 3 + 1] + t2 * wt[32 + l2 * 9 + k * 3 + 2];
+                    if (l1 == l2) {
+                        const int lo_ = i < k ? i : k, hi_ = i < k ? k : i;
+                        val += sh.lc[l1].sg[lo_ * 3 - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)];
+                    }
+                } else {
+                    const int wb = l1 == 0 ? 2 : 16;
+                    val = sh.ls[cur][l1].e[i] - (g10 * wt[wb] + g11 * wt[wb + 1] + g12 * wt[wb + 2]);
                 }
-                const bool ok = chol_solve<NS>(S6, mu);
-                if (lane == 0) {
-                    // publish nu_l = Gam_l^T mu_l
+            }
+            bool okS = true;
 #pragma unroll
-                    for (int l = 0; l < NL; ++l)
+            for (int k = 0; k < NS; ++k) {
+                const double piv = read_lane(val, k * RS + k);
+                okS = okS && (piv > 0);
+                const double inv = 1.0 / piv;
+                const double rowk = __shfl(val, k * RS + c, 64);
+                const double colk = __shfl(val, r * RS + k, 64);
+                val = (r == k) ? rowk * inv : val - (colk * inv) * rowk;
+            }
+            // nu_l[cc] = sum_rr Gamma_l[rr][cc] mu_{3l+rr}; mu_r sits in lane r*RS + NS
+            {
+                const int l = (lane < NS) ? lane / 3 : 0, cc = lane % 3;
+                double nv = 0.0;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            S2.sol[3 * l + c] = Gam[l][0][c] * mu[3 * l] + Gam[l][1][c] * mu[3 * l + 1] + Gam[l][2][c] * mu[3 * l + 2];
-                    S2.sol[NS] = bbTot;
-                    S2.sol[NS + 1] = bHbTot;
-                    S2.sol[NS + 2] = ok ? 1.0 : 0.0;
+                for (int rr = 0; rr < 3; ++rr) {
+                    const double mu_r = __shfl(val, (3 * l + rr) * RS + NS, 64);
+                    nv += wt[32 + l * 9 + rr * 3 + cc] * mu_r;
                 }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nu[k] = read_lane(nv, k); nu2[k] = NL == 2 ? read_lane(nv, 3 + k) : 0.0; }
+            }
+            double lq = 0.0;
+            if (lane < NL) lq = loop_quad(lane, S);
+            const double bHbTot = wt[1] + read_lane(lq, 0) + (NL == 2 ? read_lane(lq, 1) : 0.0);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { S2.sol[k] = nu[k]; if (NL == 2) S2.sol[3 + k] = nu2[k]; }
+                S2.sol[NS] = wt[0];
+                S2.sol[NS + 1] = bHbTot;
+                S2.sol[NS + 2] = okS ? 1.0 : 0.0;
+            }
             }
             __syncthreads();
             ++phase;
