@@ -513,7 +513,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     Pose2 edge = gauge;                              // committed pose of this wave's predecessor
     Pose2 edgeN = gauge;                             // same for the trial state
 #ifdef IPC_PHASE_TIMING
-    unsigned long long te[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+    unsigned long long te[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
 #define IPC_ETICK(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te[k] += t_ - tq; tq = t_; }
 #define IPC_ESTART() { tq = __builtin_amdgcn_s_memtime(); }
 #else
@@ -671,6 +671,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         if constexpr (NL == 2) { lo2 = sh.lc[1].lo; hi2 = sh.lc[1].hi; }
         {
             Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            IPC_ESTART()
             publish_endpoint_vec(bx, by, bth, S);
             // group 1: b^T b, b^T H b, W_1 (3), M_11 (6)            -> red[wave][0..10]
             // group 2 (pair cells): W_2 (3), M_22 (6), M_12 (6)     -> red[wave][16..30]
@@ -720,9 +721,12 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                     for (int k = 0; k < 6; ++k) { v2[3 + k] += m2 * psi[k]; v2[9 + k] += m12 * psi[k]; }
                 }
             }
+            IPC_ETICK(6)
             wave_sum16_store(v1, &S.red[wave * 32]);
             if constexpr (NL == 2) wave_sum16_store(v2, &S.red[wave * 32 + 16]);
+            IPC_ETICK(7)
             __syncthreads();
+            IPC_ETICK(8)
             ++phase;
             Se2Scratch<W, NL>& S2 = sh.scr[phase & 1];
             if (wave == 0) {
@@ -781,10 +785,14 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             for (int k = 0; k < NS; ++k) {
                 const double piv = read_lane(val, k * RS + k);
                 okS = okS && (piv > 0);
-                const double inv = 1.0 / piv;
+                // reciprocal by v_rcp_f64 + two Newton steps (~1 ulp) instead of the ~30-op IEEE divide:
+                // it sits on the serial critical path of the elimination
+                double inv = __builtin_amdgcn_rcp(piv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
                 const double rowk = __shfl(val, k * RS + c, 64);
                 const double colk = __shfl(val, r * RS + k, 64);
-                val = (r == k) ? rowk * inv : val - (colk * inv) * rowk;
+                val = (r == k) ? rowk * inv : fma(-(colk * rowk), inv, val);
             }
             // nu_l[cc] = sum_rr Gamma_l[rr][cc] mu_{3l+rr}; mu_r sits in lane r*RS + NS
             {
@@ -809,7 +817,9 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 S2.sol[NS + 2] = okS ? 1.0 : 0.0;
             }
             }
+            IPC_ETICK(9)
             __syncthreads();
+            IPC_ETICK(10)
             ++phase;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { nu[k] = S2.sol[k]; nu2[k] = NL == 2 ? S2.sol[3 + k] : 0.0; }
@@ -1037,6 +1047,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 4, (unsigned long long)it_done);
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 5, (unsigned long long)evals);
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 8 + k, te[k]);
+        for (int k = 6; k < 11; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 18 + k, te[k]);
     }
     if (tid == 64 * (W - 1) && P.dbg)
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg) + 16 + k, te[k]);

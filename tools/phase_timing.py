@@ -8,8 +8,8 @@ from ipc_amd.consensus import IPC
 g, cfg, desc = build_workload(sys.argv[1] if len(sys.argv) > 1 else "C1")
 eng = IPC(g, cfg, device=0)
 eng.run()
-out = np.zeros(24, dtype=np.uint64)
-eng.lib.ipc_dbg_read(eng.h, out.ctypes.data_as(C.c_void_p), 24)
+out = np.zeros(32, dtype=np.uint64)
+eng.lib.ipc_dbg_read(eng.h, out.ctypes.data_as(C.c_void_p), 32)
 tA, tB, tC, tT, its, ev = [float(x) for x in out[:6]]
 tot = tA + tB + tC + tT
 print("cycles (thread 0 of every cell): A %.1f%%  B %.1f%%  C %.1f%%  trials+eval %.1f%%" % (100*tA/tot, 100*tB/tot, 100*tC/tot, 100*tT/tot))
@@ -18,3 +18,5 @@ names = ["update+publish", "barrier1", "neighbour+errors", "loop_eval+wave_sum",
 for tag, base in (("wave 0", 8), ("last wave", 16)):
     t = [float(x) for x in out[base:base + 6]]
     print(tag, "per evaluation:", "  ".join("%s %.0f" % (n, v / ev) for n, v in zip(names, t)), " total %.0f" % (sum(t) / ev))
+tb = [float(x) for x in out[24:29]]
+print("wave 0 per iteration, phase B:", "  ".join("%s %.0f" % (n, v / its) for n, v in zip(["partials", "packed reduce", "barrier", "solve", "barrier"], tb)))
