@@ -59,6 +59,11 @@ def build_workload(name):
         g = synth.inject_outliers(synth.sphere_like(), 2000, seed=2000)
         cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=2450)
         desc = "sphere2500-like SE3 synthetic (V=2500, 2450 true loops) + 2000 injected outliers"
+    elif name == "C4m":
+        g = synth.inject_outliers(synth.sphere_like(), 200, seed=200)
+        g = g.subset(np.concatenate([np.arange(0, 2450, 10), np.arange(2450, g.N)]))
+        cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=245)
+        desc = "sphere2500-like SE3 synthetic (V=2500), every 10th true loop (245) + 200 injected outliers"
     elif name == "C4s":
         g = synth.inject_outliers(synth.sphere_like(rings=20, per_ring=25, radius=20.0), 60, seed=60)
         g2 = g.subset(np.concatenate([np.arange(0, 475, 8), np.arange(475, g.N)]))
