@@ -250,6 +250,10 @@ struct Se3Shared {
     Se3Scratch<W, NL> scr[2];
     LoopConst3 lc[NL];
     LoopState3 ls[2][NL];
+    double w0tot[80];         // wave-0 temporaries of the capacitance solve: totals,
+    double w0gam[NL][36];     //   Gamma_l (6x6 each),
+    double w0aug[NL * 6][NL * 6 + 1];   // the augmented system,
+    double w0mu[NL * 6];      //   its solution
 };
 
 // SPD solve by Cholesky, N = 6 or 12 (wave 0 only)
@@ -615,15 +619,27 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                 }
             }
         }
-        // ---- phase B: partials b^T b, b^T H b, d = sum G e, S = sum G Sg G^T; solve on wave 0 ----
+        // ---- phase B: b^T b, b^T H b and the loop-free capacitance partials; solve on wave 0 ----
+        // G_{l,j} = Gamma_l Phi_j with (poses shifted by the gauge position o, t~ = t - o)
+        //   Phi_j   = T(X~_j^-1) D(E_j)^-1 = [[U, K],[0, Vq]],  U = R_j RE_j^T, Vq = R_j Q_j^-1, K = 2 [t~_j]x Vq
+        //   Gamma_l = sigma_l D(E_l) T(X~_to) = sigma_l [[RE_l R_to^T, -2 RE_l R_to^T [t~_to]x],[0, Q_l R_to^T]]
+        // so per edge only Psi_j = Phi_j Cov_j Phi_j^T (21 values) and w_j = Phi_j e_j (6) are
+        // accumulated per loop range; S_ll' = Gamma_l M_ll' Gamma_l'^T, d_l = e_l - Gamma_l W_l.
         double bb, bHb, alpha, hsdNorm;
-        double mu[NS];
+        double nu[NL][6];                             // Gamma_l^T mu_l
+        int rlo[NL], rhi[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { rlo[l] = sh.lc[l].lo; rhi[l] = sh.lc[l].hi; }
         {
             Se3Scratch<W, NL>& S = sh.scr[phase & 1];
             publish_endpoint_vec(b, S);
-            double part[NG * 16];
+            // value layout: [0] b^T b, [1] b^T H b, [2..8) W_1, [8..29) M_11; pair cells: [29..35) W_2,
+            // [35..56) M_22, [56..77) M_12
+            constexpr int NV = NL == 1 ? 29 : 77;
+            constexpr int NGR = (NV + 15) / 16;
+            double part[NGR * 16];
 #pragma unroll
-            for (int k = 0; k < NG * 16; ++k) part[k] = 0.0;
+            for (int k = 0; k < NGR * 16; ++k) part[k] = 0.0;
             double cb[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) cb[k] = pb[k];
@@ -647,67 +663,71 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                 double w[6];
                 se3_apply_J(E, qb, b[s], w);
                 part[1] += sym6_quad(om, w);
-                // G_l (6x6, lower-left block zero) for each loop; rows kept as full 6-vectors
-                double G[NL][6][6];
-                const int j = jbase + s * 64;
+                // Phi = [[U, K],[0, Vq]]
+                double U[9], Qi[9], Vq[9], K[9];
+                m3_mult(X[s].R, E.RE, U);
+                {
+                    const double iw = 1.0 / E.qw;
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const LoopConst3& q = sh.lc[l];
-                    const LoopState3& st = sh.ls[cur][l];
-                    const bool on = j > q.lo && j <= q.hi;
-                    const double sgn = on ? q.sigma : 0.0;
-                    // (Rr, tr) = X_j^-1 X_to
-                    double Rr[9], tr[3], d3[3] = {st.pt.t[0] - X[s].t[0], st.pt.t[1] - X[s].t[1], st.pt.t[2] - X[s].t[2]};
-                    m3_tmul(X[s].R, st.pt.R, Rr);
-                    m3_tvec(X[s].R, d3, tr);
-                    // columns of G: G x = sgn * D_l T Dinv_j x, applied to the 6 unit vectors
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) Qi[3 * i + k] = E.qv[i] * E.qv[k] * iw + (i == k ? E.qw : 0.0);
+                    Qi[1] += E.qv[2]; Qi[2] -= E.qv[1];      // - [v]x
+                    Qi[3] -= E.qv[2]; Qi[5] += E.qv[0];
+                    Qi[6] += E.qv[1]; Qi[7] -= E.qv[0];
+                }
+                m3_mul(X[s].R, Qi, Vq);
+                const double tt[3] = {X[s].t[0] - gauge.t[0], X[s].t[1] - gauge.t[1], X[s].t[2] - gauge.t[2]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {             // K[:,c] = 2 tt x Vq[:,c]
+                    K[0 + c] = 2 * (tt[1] * Vq[6 + c] - tt[2] * Vq[3 + c]);
+                    K[3 + c] = 2 * (tt[2] * Vq[0 + c] - tt[0] * Vq[6 + c]);
+                    K[6 + c] = 2 * (tt[0] * Vq[3 + c] - tt[1] * Vq[0 + c]);
+                }
+                auto phi = [&](int r, int k) -> double {  // Phi[r][k]
+                    if (r < 3) return k < 3 ? U[3 * r + k] : K[3 * r + (k - 3)];
+                    return k < 3 ? 0.0 : Vq[3 * (r - 3) + (k - 3)];
+                };
+                // PS = Phi Cov (rows r, columns c), Psi = PS Phi^T (upper triangle, sym6 order)
+                double psi[21], wj[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double ps[6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
-                        double u[6] = {0, 0, 0, 0, 0, 0}, y[6], z[6], gcol[6];
-                        u[c] = 1.0;
-                        se3_Dinv(E, u, y);
-                        // z = T y = (Rr^T (y_t - 2 tr x y_q), Rr^T y_q)
-                        double cr[3];
-                        cross3(tr, y + 3, cr);
-                        double yt[3] = {y[0] - 2 * cr[0], y[1] - 2 * cr[1], y[2] - 2 * cr[2]};
-                        m3_tvec(Rr, yt, z);
-                        m3_tvec(Rr, y + 3, z + 3);
-                        // gcol = D_l z
-                        double c2[3];
-                        m3_vec(st.RE, z, gcol);
-                        cross3(st.qv, z + 3, c2);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) gcol[3 + i] = st.qw * z[3 + i] + c2[i];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) G[l][r][c] = sgn * gcol[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
                         double acc = 0.0;
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) acc += G[l][r][c] * e[s][c];
-                        part[2 + 6 * l + r] += acc;
+                        for (int a = (r < 3 ? 0 : 3); a < 6; ++a) acc += phi(r, a) * sg[sym6_idx(a, c)];
+                        ps[c] = acc;
                     }
+#pragma unroll
+                    for (int c = r; c < 6; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = (c < 3 ? 0 : 3); k < 6; ++k) acc += ps[k] * phi(c, k);
+                        psi[sym6_idx(r, c)] = acc;
+                    }
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = (r < 3 ? 0 : 3); a < 6; ++a) acc += phi(r, a) * e[s][a];
+                    wj[r] = acc;
                 }
-                // S upper triangle: H = G Sg, S[r][c] = H_r . G_c
-                int idx = 2 + NS;
+                const int j = jbase + s * 64;
+                const double m1 = (j > rlo[0] && j <= rhi[0]) ? 1.0 : 0.0;
 #pragma unroll
-                for (int r = 0; r < NS; ++r) {
-                    const int l1 = r / 6, r1 = r % 6;
-                    double hrow[6];
-                    sym6_mul(sg, G[l1][r1], hrow);
+                for (int k = 0; k < 6; ++k) part[2 + k] += m1 * wj[k];
 #pragma unroll
-                    for (int c = r; c < NS; ++c) {
-                        const int l2 = c / 6, r2 = c % 6;
-                        double acc = 0.0;
+                for (int k = 0; k < 21; ++k) part[8 + k] += m1 * psi[k];
+                if constexpr (NL == 2) {
+                    const double m2 = (j > rlo[1] && j <= rhi[1]) ? 1.0 : 0.0, m12 = m1 * m2;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) acc += hrow[k] * G[l2][r2][k];
-                        part[idx++] += acc;
-                    }
+                    for (int k = 0; k < 6; ++k) part[29 + k] += m2 * wj[k];
+#pragma unroll
+                    for (int k = 0; k < 21; ++k) { part[35 + k] += m2 * psi[k]; part[56 + k] += m12 * psi[k]; }
                 }
             }
 #pragma unroll
-            for (int gq = 0; gq < NG; ++gq) {
+            for (int gq = 0; gq < NGR; ++gq) {
                 double v16[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) v16[k] = part[16 * gq + k];
@@ -717,49 +737,133 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             ++phase;
             Se3Scratch<W, NL>& S2 = sh.scr[phase & 1];
             if (wave == 0) {
-                double tot[KR];
+                constexpr int RS = NS + 1;
+                // totals
 #pragma unroll
-                for (int k0 = 0; k0 < KR; k0 += 64) {
-                    double acc = 0.0;
-                    if (k0 + lane < KR) {
+                for (int k0 = 0; k0 < NV; k0 += 64) {
+                    if (k0 + lane < NV) {
+                        double acc = 0.0;
 #pragma unroll
                         for (int w = 0; w < W; ++w) acc += S.red[w * 96 + k0 + lane];
+                        sh.w0tot[k0 + lane] = acc;
                     }
-#pragma unroll
-                    for (int k = k0; k < KR && k < k0 + 64; ++k) tot[k] = read_lane(acc, k - k0);
                 }
-                double S6[NS][NS];
-                int idx = 2 + NS;
-#pragma unroll
-                for (int r = 0; r < NS; ++r)
-#pragma unroll
-                    for (int c = r; c < NS; ++c) { S6[r][c] = tot[idx]; S6[c][r] = tot[idx]; ++idx; }
-                double bHbTot = tot[1];
+                // Gamma_l entries (one lane per entry, one round per loop)
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
-                    const LoopConst3& q = sh.lc[l];
-                    const LoopState3& st = sh.ls[cur][l];
+                    if (lane < 36) {
+                        const int r = lane / 6, c = lane % 6;
+                        const LoopConst3& q = sh.lc[l];
+                        const LoopState3& st = sh.ls[cur][l];
+                        const double tt[3] = {st.pt.t[0] - gauge.t[0], st.pt.t[1] - gauge.t[1], st.pt.t[2] - gauge.t[2]};
+                        double g = 0.0;
+                        if (r < 3) {
+                            // P = RE Rto^T, row r
+                            double Pr[3];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) S6[6 * l + r][6 * l + c] += q.sg[sym6_idx(r, c)];
-                        mu[6 * l + r] = st.e[r] - tot[2 + 6 * l + r];
+                            for (int k = 0; k < 3; ++k) Pr[k] = st.RE[3 * r] * st.pt.R[3 * k] + st.RE[3 * r + 1] * st.pt.R[3 * k + 1] + st.RE[3 * r + 2] * st.pt.R[3 * k + 2];
+                            if (c < 3) g = Pr[c];
+                            else {
+                                // -2 (P [tt]x)[r][c-3];  [tt]x = [[0,-t2,t1],[t2,0,-t0],[-t1,t0,0]]
+                                const int cc = c - 3;
+                                const double col[3] = {cc == 0 ? 0.0 : (cc == 1 ? -tt[2] : tt[1]),
+                                                       cc == 0 ? tt[2] : (cc == 1 ? 0.0 : -tt[0]),
+                                                       cc == 0 ? -tt[1] : (cc == 1 ? tt[0] : 0.0)};
+                                g = -2 * (Pr[0] * col[0] + Pr[1] * col[1] + Pr[2] * col[2]);
+                            }
+                        } else if (c >= 3) {
+                            // (Q Rto^T)[r-3][c-3],  Q = w I + [v]x
+                            const int rr = r - 3, cc = c - 3;
+                            double Qr[3] = {rr == 0 ? st.qw : (rr == 1 ? st.qv[2] : -st.qv[1]),
+                                            rr == 0 ? -st.qv[2] : (rr == 1 ? st.qw : st.qv[0]),
+                                            rr == 0 ? st.qv[1] : (rr == 1 ? -st.qv[0] : st.qw)};
+                            g = Qr[0] * st.pt.R[3 * cc] + Qr[1] * st.pt.R[3 * cc + 1] + Qr[2] * st.pt.R[3 * cc + 2];
+                        }
+                        sh.w0gam[l][lane] = q.sigma * g;
                     }
-                    bHbTot += loop_quad(l, S);
                 }
-                const bool ok = chol_solve_n<NS>(S6, mu);
-                if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // augmented system: one entry per (lane, round)
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) S2.sol[k] = mu[k];
-                    S2.sol[NS] = tot[0];
+                for (int q0 = 0; q0 < NS * RS; q0 += 64) {
+                    const int idx = q0 + lane;
+                    if (idx < NS * RS) {
+                        const int r = idx / RS, c = idx % RS;
+                        const int l1 = r / 6, i = r % 6;
+                        const double* g1 = &sh.w0gam[l1][6 * i];
+                        double val;
+                        if (c < NS) {
+                            const int l2 = c / 6, k = c % 6;
+                            const double* g2 = &sh.w0gam[l2][6 * k];
+                            const int mb = l1 == l2 ? (l1 == 0 ? 8 : 35) : 56;
+                            val = 0.0;
+#pragma unroll
+                            for (int bq = 0; bq < 6; ++bq) {
+                                double t = 0.0;
+#pragma unroll
+                                for (int a = 0; a < 6; ++a) t += g1[a] * sh.w0tot[mb + sym6_idx(a, bq)];
+                                val += t * g2[bq];
+                            }
+                            if (l1 == l2) val += sh.lc[l1].sg[sym6_idx(i, k)];
+                        } else {
+                            const int wb = l1 == 0 ? 2 : 29;
+                            double t = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) t += g1[a] * sh.w0tot[wb + a];
+                            val = sh.ls[cur][l1].e[i] - t;
+                        }
+                        sh.w0aug[r][c] = val;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // Gauss-Jordan, one row per lane
+                double row[RS];
+                const int rl = lane < NS ? lane : 0;
+#pragma unroll
+                for (int c = 0; c < RS; ++c) row[c] = sh.w0aug[rl][c];
+                bool okS = true;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const double piv = read_lane(row[k], k);
+                    okS = okS && (piv > 0);
+                    double inv = __builtin_amdgcn_rcp(piv);
+                    inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                    inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                    const double f = row[k] * inv;
+#pragma unroll
+                    for (int c = k; c < RS; ++c) {
+                        const double pr = read_lane(row[c], k);
+                        row[c] = (lane == k) ? pr * inv : fma(-f, pr, row[c]);
+                    }
+                }
+                if (lane < NS) sh.w0mu[lane] = row[NS];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double lq = 0.0;
+                if (lane < NL) lq = loop_quad(lane, S);
+                double bHbTot = sh.w0tot[1] + read_lane(lq, 0);
+                if (NL == 2) bHbTot += read_lane(lq, 1);
+                if (lane < NS) {
+                    const int l = lane / 6, c = lane % 6;
+                    double t = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) t += sh.w0gam[l][6 * r + c] * sh.w0mu[6 * l + r];
+                    S2.sol[lane] = t;
+                }
+                if (lane == 0) {
+                    S2.sol[NS] = sh.w0tot[0];
                     S2.sol[NS + 1] = bHbTot;
-                    S2.sol[NS + 2] = ok ? 1.0 : 0.0;
+                    S2.sol[NS + 2] = okS ? 1.0 : 0.0;
                 }
             }
             __syncthreads();
             ++phase;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) mu[k] = S2.sol[k];
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nu[l][k] = S2.sol[6 * l + k];
             bb = S2.sol[NS];
             bHb = S2.sol[NS + 1];
             if (S2.sol[NS + 2] == 0.0) { flags |= 2; break; }
@@ -781,40 +885,36 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                 Edge3 E;
                 se3_edge(A[s], X[s], Rz, tz, E);
                 ld_sym(G_SG, s, sg);
-                // w = sum_l G_l^T mu_l,  G^T mu = sgn * Dinv_j^T T^T D_l^T mu
-                double wv[6] = {0, 0, 0, 0, 0, 0};
+                // sum_l G_l^T mu_l = Phi_j^T n,  n = sum_l mask_l nu_l;
+                // Phi^T n = (U^T n_t, Vq^T (n_q - 2 t~ x n_t))
                 const int j = jbase + s * 64;
+                double nn[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
-                    const LoopConst3& q = sh.lc[l];
-                    const LoopState3& st = sh.ls[cur][l];
-                    const bool on = j > q.lo && j <= q.hi;
-                    if (!on) continue;
-                    double Rr[9], tr[3], d3[3] = {st.pt.t[0] - X[s].t[0], st.pt.t[1] - X[s].t[1], st.pt.t[2] - X[s].t[2]};
-                    m3_tmul(X[s].R, st.pt.R, Rr);
-                    m3_tvec(X[s].R, d3, tr);
-                    // y = D_l^T mu_l
-                    double y[6], c1[3];
-                    m3_tvec(st.RE, &mu[6 * l], y);
-                    cross3(st.qv, &mu[6 * l + 3], c1);
+                    const double ml = (j > rlo[l] && j <= rhi[l]) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) y[3 + i] = st.qw * mu[6 * l + 3 + i] - c1[i];
-                    // z = T^T y = (Rr y_t, 2 tr x (Rr y_t) + Rr y_q)
-                    double z[6], r3[3], c2[3];
-                    m3_vec(Rr, y, z);
-                    m3_vec(Rr, y + 3, r3);
-                    cross3(tr, z, c2);
+                    for (int k = 0; k < 6; ++k) nn[k] += ml * nu[l][k];
+                }
+                double wv[6];
+                {
+                    double U[9], Qi[9], Vq[9];
+                    m3_mult(X[s].R, E.RE, U);
+                    const double iw = 1.0 / E.qw;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) z[3 + i] = r3[i] + 2 * c2[i];
-                    // Dinv_j^T z = (RE z_t, (w I + [v]x + v v^T / w) z_q)
-                    double o[6], c3[3];
-                    m3_vec(E.RE, z, o);
-                    cross3(E.qv, z + 3, c3);
-                    const double vz = (E.qv[0] * z[3] + E.qv[1] * z[4] + E.qv[2] * z[5]) / E.qw;
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) o[3 + i] = E.qw * z[3 + i] + c3[i] + E.qv[i] * vz;
+                        for (int k = 0; k < 3; ++k) Qi[3 * i + k] = E.qv[i] * E.qv[k] * iw + (i == k ? E.qw : 0.0);
+                    Qi[1] += E.qv[2]; Qi[2] -= E.qv[1];
+                    Qi[3] -= E.qv[2]; Qi[5] += E.qv[0];
+                    Qi[6] += E.qv[1]; Qi[7] -= E.qv[0];
+                    m3_mul(X[s].R, Qi, Vq);
+                    const double tt[3] = {X[s].t[0] - gauge.t[0], X[s].t[1] - gauge.t[1], X[s].t[2] - gauge.t[2]};
+                    double cr[3], y3[3];
+                    cross3(tt, nn, cr);
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) wv[k] += q.sigma * o[k];
+                    for (int k = 0; k < 3; ++k) y3[k] = nn[3 + k] - 2 * cr[k];
+                    m3_tvec(U, nn, wv);
+                    m3_tvec(Vq, y3, wv + 3);
                 }
                 double v[6], u[6], rho[6];
                 sym6_mul(sg, wv, v);
@@ -877,15 +977,8 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             }
             ++phase;
             // h (body frame) and the per-iteration scalars |h|^2, b.h, h^T H h
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-            double ch[6];                               // h of the predecessor pose (body frame of that pose)
-            {
-                double hw[3], ht[3];
-                m3_tvec(edge.R, bo, hw);
-                m3_tvec(edge.R, bt, ht);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { ch[k] = ht[k]; ch[3 + k] = hw[k]; }
-            }
+            // |h|^2 and b.h; h^T H h = b^T h since h solves H h = b
+            double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
                 if (valid[s]) {
@@ -895,40 +988,23 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                     for (int k = 0; k < 3; ++k) { om3[k] = lo_[s][k] + bo[k]; ta3[k] = lt_[s][k] + bt[k] + 2 * c[k]; }
                     m3_tvec(X[s].R, ta3, &h[s][0]);
                     m3_tvec(X[s].R, om3, &h[s][3]);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { p0 += h[s][k] * h[s][k]; p1 += b[s][k] * h[s][k]; }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) h[s][k] = 0.0;
                 }
-                double qh[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    qh[k] = lane_prev(h[s][k], ch[k]);
-                    if (s + 1 < M) ch[k] = read_lane(h[s][k], 63);
-                }
-                if (!valid[s]) continue;
-                double Rz[9], tz[3], om[21], w[6];
-                ld_rz(s, Rz, tz);
-                Edge3 E;
-                se3_edge(A[s], X[s], Rz, tz, E);
-                ld_sym(G_OM, s, om);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { p0 += h[s][k] * h[s][k]; p1 += b[s][k] * h[s][k]; }
-                se3_apply_J(E, qh, h[s], w);
-                p2 += sym6_quad(om, w);
             }
             Se3Scratch<W, NL>& S2 = sh.scr[phase & 1];
-            publish_endpoint_vec(h, S2);
-            p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-            if (lane == 0) { S2.red[wave] = p0; S2.red[16 + wave] = p1; S2.red[32 + wave] = p2; }
+            p0 = wave_sum(p0); p1 = wave_sum(p1);
+            if (lane == 0) { S2.red[wave] = p0; S2.red[16 + wave] = p1; }
             __syncthreads();
-            double tot[3];
-            gather_totals<3>(S2.red, W, tot);
-            hHh = tot[2];
-#pragma unroll
-            for (int l = 0; l < NL; ++l) hHh += loop_quad(l, S2);
+            double tot[2];
+            gather_totals<2>(S2.red, W, tot);
             ++phase;
             hgnNorm = sqrt(tot[0]);
             bh = tot[1];
+            hHh = bh;
         }
 
         // ---- trial loop ----
@@ -1003,8 +1079,10 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             ++evals;
             const double nonLinearGain = currentChi - newChi;
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
-            const double rho = nonLinearGain / linearGain;
-            if (rho > 0) {
+            const bool linPos = linearGain > 0;
+            auto rho_gt = [&](double t) { return linPos ? nonLinearGain > t * linearGain : nonLinearGain < t * linearGain; };
+            auto rho_lt = [&](double t) { return linPos ? nonLinearGain < t * linearGain : nonLinearGain > t * linearGain; };
+            if (rho_gt(0.0)) {
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
@@ -1016,8 +1094,8 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                     for (int k = 0; k < 6; ++k) e[s][k] = en[s][k];
                 }
             }
-            if (rho > 0.75) delta = fmax(delta, 3 * hdlNorm);
-            else if (rho < 0.25) delta *= 0.5;
+            if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
+            else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
                 if (stepType == 0) {
                     while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
