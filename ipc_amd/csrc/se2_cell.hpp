@@ -257,7 +257,7 @@ struct Se2Scratch {           // per-phase hand-off, double buffered
     double lo_vec[W][3];      // vector held by lane 0 / slot 0
     double lvec[NL][2][3];    // vectors at the loop end points (from, to)
     double scan[W][5];        // per-wave scan totals
-    double sol[NL * 3 + 3];   // nu = Gamma^T mu per loop, b^T b, b^T H b, ok flag (written by wave 0)
+    double sol[NL * 3 + 3 + NL];   // nu per loop, b^T b, b^T H b (odometry part), ok flag, loop parts of b^T H b
 };
 
 // Chain records of the cell are staged once into LDS (17 doubles per edge) when the variant's
@@ -722,6 +722,20 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
             }
             IPC_ETICK(6)
+            // Gamma_l only depends on the loop state: the last wave (usually the least loaded one)
+            // prepares it for wave 0 ahead of the barrier.  Lane l*9+i*3+a : Gamma_l[i][a].
+            if (wave == W - 1 && lane < NL * 9) {
+                const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
+                const LoopConst& q = sh.lc[l];
+                const LoopState& st = sh.ls[cur][l];
+                const double Aq = st.pf[3] * q.cz - st.pf[4] * q.sz, Bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
+                const double Kx = -(st.pt[1] - gauge.y), Ky = st.pt[0] - gauge.x;
+                double g;
+                if (i == 0) g = a == 0 ? Aq : (a == 1 ? Bq : Aq * Kx + Bq * Ky);
+                else if (i == 1) g = a == 0 ? -Bq : (a == 1 ? Aq : -Bq * Kx + Aq * Ky);
+                else g = a == 2 ? 1.0 : 0.0;
+                sh.wtmp[0][32 + lane] = q.sigma * g;
+            }
             wave_sum16_store(v1, &S.red[wave * 32]);
             if constexpr (NL == 2) wave_sum16_store(v2, &S.red[wave * 32 + 16]);
             IPC_ETICK(7)
@@ -734,26 +748,12 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             //   lane t < 32      : total of partial t over the waves          -> wtmp[t]
             //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> wtmp[32 + .]
             //   lane r*(NS+1)+c  : S[r][c] (c < NS) / rhs d[r] (c == NS), then Gauss-Jordan in place
-            double* wt = sh.wtmp[wave];
-            {
+            double* wt = sh.wtmp[0];
+            if (lane < 32) {
                 double acc = 0.0;
-                if (lane < 32) {
 #pragma unroll
-                    for (int w = 0; w < W; ++w) acc += S.red[w * 32 + lane];
-                    wt[lane] = acc;
-                }
-                if (lane < NL * 9) {
-                    const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
-                    const LoopConst& q = sh.lc[l];
-                    const LoopState& st = sh.ls[cur][l];
-                    const double Aq = st.pf[3] * q.cz - st.pf[4] * q.sz, Bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
-                    const double Kx = -(st.pt[1] - gauge.y), Ky = st.pt[0] - gauge.x;
-                    double g;
-                    if (i == 0) g = a == 0 ? Aq : (a == 1 ? Bq : Aq * Kx + Bq * Ky);
-                    else if (i == 1) g = a == 0 ? -Bq : (a == 1 ? Aq : -Bq * Kx + Aq * Ky);
-                    else g = a == 2 ? 1.0 : 0.0;
-                    wt[32 + lane] = q.sigma * g;
-                }
+                for (int w = 0; w < W; ++w) acc += S.red[w * 32 + lane];
+                wt[lane] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -806,17 +806,16 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { nu[k] = read_lane(nv, k); nu2[k] = NL == 2 ? read_lane(nv, 3 + k) : 0.0; }
             }
-            double lq = 0.0;
-            if (lane < NL) lq = loop_quad(lane, S);
-            const double bHbTot = wt[1] + read_lane(lq, 0) + (NL == 2 ? read_lane(lq, 1) : 0.0);
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { S2.sol[k] = nu[k]; if (NL == 2) S2.sol[3 + k] = nu2[k]; }
                 S2.sol[NS] = wt[0];
-                S2.sol[NS + 1] = bHbTot;
+                S2.sol[NS + 1] = wt[1];
                 S2.sol[NS + 2] = okS ? 1.0 : 0.0;
             }
             }
+            // the loops' share of b^T H b, in parallel on another wave
+            if (wave == (W > 1 ? 1 : 0) && lane < NL) S2.sol[NS + 3 + lane] = loop_quad(lane, S);
             IPC_ETICK(9)
             __syncthreads();
             IPC_ETICK(10)
@@ -824,7 +823,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
             for (int k = 0; k < 3; ++k) { nu[k] = S2.sol[k]; nu2[k] = NL == 2 ? S2.sol[3 + k] : 0.0; }
             bb = S2.sol[NS];
-            bHb = S2.sol[NS + 1];
+            bHb = S2.sol[NS + 1] + S2.sol[NS + 3] + (NL == 2 ? S2.sol[NS + 4] : 0.0);
             if (S2.sol[NS + 2] == 0.0) { flags |= 2; break; }
             alpha = bb / bHb;
             hsdNorm = sqrt(alpha * alpha * bb);
