@@ -127,6 +127,53 @@ int ipc_solver_time_ms(ipc_engine_t* h, double* ms, int* launches);
 
 int ipc_synchronize(ipc_engine_t* h);
 
+/* ---- faithful incremental mode and final map -------------------
+ * The reference's own sequential algorithm on the GPU: state = current pose estimates + the
+ * consensus set, one cluster solve per candidate.  SE2 engines only for now (SE3 returns
+ * IPC_ERR_LIMIT). */
+
+/* Outcome of one cluster solve. */
+typedef struct {
+    int    lo, hi;           /* vertex-id span of the cluster                           */
+    int    n_cluster_loops;  /* accepted edges absorbed into the cluster (0: fast path) */
+    int    iterations, tries, flags;   /* as in ipc_cell_info_t                         */
+    double max_chi2;         /* max edge chi2 after the optimisation                    */
+    double chi2_total;       /* sum of chi2 after the optimisation                      */
+    double chi2_initial;     /* sum of chi2 before it                                   */
+} ipc_check_info_t;
+
+/* Back to the state right after IPC::IPC (src/consensus.cpp:23-27): current poses = open-loop
+ * propagation, empty consensus set.  Implicit in ipc_set_candidates(). */
+int ipc_incremental_reset(ipc_engine_t* h);
+
+/* Replaces IPC<EDGE,VERTEX>::agreementCheck (src/consensus.cpp:43-75) for candidate k (FILE
+ * index): computeIndependentSubgraph (:124-171), fast/slow threshold and iteration base
+ * (:50-52), isAgreeingWithCurrentState on chain [lo,hi] + cluster loops + candidate from the
+ * current poses (consensus_utils.cpp:7-22); on agreement the poses are kept, k joins the
+ * consensus set and the tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71);
+ * otherwise the state is untouched.  *agrees = 1 / 0.  info may be NULL. */
+int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_check_info_t* info);
+
+/* IPC::getMaxConsensusSet (include/ipc/consensus.hpp:16): candidate FILE indices in set order. */
+int ipc_consensus_size(ipc_engine_t* h, int* n);
+int ipc_consensus_set(ipc_engine_t* h, int* out);
+
+/* IPC::removeEdgeFromCnS (src/consensus.cpp:77-96): drops the first member joining the same
+ * vertex pair as candidate k; *removed = 1 if one was found. */
+int ipc_remove_from_consensus(ipc_engine_t* h, int k, int* removed);
+/* IPC::addEdgeToCnS (src/consensus.cpp:98-119): appends k unless a member joins the same vertex
+ * pair, then re-sorts the set by cmpEdgesTime (stable). */
+int ipc_add_to_consensus(ipc_engine_t* h, int k);
+
+/* Current pose estimates (the g2o vertex estimates the reference mutates), SE2 [V][3]. */
+int ipc_current_poses(ipc_engine_t* h, double* poses_out);
+
+/* Final map (src/simulation.cpp:50-65): open-loop guess, odometry information back to
+ * (info * s) / s, every candidate with accepted[k] != 0, optimize(iterations) with vertex 0
+ * fixed (the harness uses 1000).  poses_out [V][3] and info may be NULL. */
+int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int iterations, double* poses_out,
+                       ipc_check_info_t* info);
+
 #ifdef __cplusplus
 }
 #endif

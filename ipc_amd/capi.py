@@ -17,6 +17,8 @@ SYMBOLS = [
     "ipc_last_error", "ipc_create", "ipc_destroy", "ipc_set_candidates", "ipc_candidate_order",
     "ipc_initial_poses", "ipc_rows_per_rank", "ipc_solve_rows", "ipc_assemble_matrix", "ipc_set_max",
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solver_time_ms", "ipc_synchronize",
+    "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
+    "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
 ]
 
 
@@ -30,6 +32,12 @@ class CellInfo(C.Structure):
     _fields_ = [("i", C.c_int), ("j", C.c_int), ("lo", C.c_int), ("hi", C.c_int),
                 ("max_chi2", C.c_double), ("chi2_total", C.c_double),
                 ("iterations", C.c_int), ("tries", C.c_int), ("flags", C.c_int), ("evals", C.c_int)]
+
+
+class CheckInfo(C.Structure):
+    _fields_ = [("lo", C.c_int), ("hi", C.c_int), ("n_cluster_loops", C.c_int), ("iterations", C.c_int),
+                ("tries", C.c_int), ("flags", C.c_int), ("max_chi2", C.c_double), ("chi2_total", C.c_double),
+                ("chi2_initial", C.c_double)]
 
 
 CELL_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("max_chi2", "<f8"),
@@ -68,6 +76,14 @@ def load():
     lib.ipc_cell_info.argtypes = [vp, vp, ip]
     lib.ipc_solver_time_ms.argtypes = [vp, C.POINTER(dp), C.POINTER(ip)]
     lib.ipc_synchronize.argtypes = [vp]
+    lib.ipc_incremental_reset.argtypes = [vp]
+    lib.ipc_agreement_check.argtypes = [vp, ip, C.POINTER(ip), C.POINTER(CheckInfo)]
+    lib.ipc_consensus_size.argtypes = [vp, C.POINTER(ip)]
+    lib.ipc_consensus_set.argtypes = [vp, vp]
+    lib.ipc_remove_from_consensus.argtypes = [vp, ip, C.POINTER(ip)]
+    lib.ipc_add_to_consensus.argtypes = [vp, ip]
+    lib.ipc_current_poses.argtypes = [vp, vp]
+    lib.ipc_final_optimize.argtypes = [vp, vp, ip, vp, C.POINTER(CheckInfo)]
     assert C.sizeof(CellInfo) == CELL_DTYPE.itemsize
     _lib = lib
     return lib

@@ -93,6 +93,53 @@ class IPC:
         """Candidate indices in acceptance order (reference consensus.hpp:16)."""
         return self._max_consensus_set
 
+    # ---- the reference's own per-candidate interface (faithful incremental mode) -------------
+    def reset(self):
+        """State right after the constructor (reference src/consensus.cpp:23-27)."""
+        capi.check(self.lib.ipc_incremental_reset(self.h))
+        self._max_consensus_set = np.zeros(0, dtype=np.int32)
+
+    def agreementCheck(self, k, with_info=False):
+        """IPC::agreementCheck (reference src/consensus.cpp:43-75) for candidate k (file index):
+        cluster solve from the current state on the GPU; True when every edge passes."""
+        ok, info = C.c_int(0), capi.CheckInfo()
+        capi.check(self.lib.ipc_agreement_check(self.h, int(k), C.byref(ok), C.byref(info)))
+        self._max_consensus_set = self._consensus()
+        return (bool(ok.value), info) if with_info else bool(ok.value)
+
+    def _consensus(self):
+        n = C.c_int(0)
+        capi.check(self.lib.ipc_consensus_size(self.h, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        capi.check(self.lib.ipc_consensus_set(self.h, _p(out)))
+        return out[:n.value]
+
+    def removeEdgeFromCnS(self, k):
+        """IPC::removeEdgeFromCnS (reference src/consensus.cpp:77-96)."""
+        r = C.c_int(0)
+        capi.check(self.lib.ipc_remove_from_consensus(self.h, int(k), C.byref(r)))
+        self._max_consensus_set = self._consensus()
+        return bool(r.value)
+
+    def addEdgeToCnS(self, k):
+        """IPC::addEdgeToCnS (reference src/consensus.cpp:98-119)."""
+        capi.check(self.lib.ipc_add_to_consensus(self.h, int(k)))
+        self._max_consensus_set = self._consensus()
+
+    def current_poses(self):
+        out = np.zeros((self.graph.V, 3))
+        capi.check(self.lib.ipc_current_poses(self.h, _p(out)))
+        return out
+
+    def final_optimize(self, accepted, iterations=1000):
+        """The harness's final map (reference src/simulation.cpp:50-65): returns (poses [V,3],
+        CheckInfo with chi2_total)."""
+        acc = np.ascontiguousarray(accepted, dtype=np.uint8)
+        out = np.zeros((self.graph.V, 3))
+        info = capi.CheckInfo()
+        capi.check(self.lib.ipc_final_optimize(self.h, _p(acc), int(iterations), _p(out), C.byref(info)))
+        return out, info
+
     # ---- device-pointer stages (multi-GPU plumbing lives in ipc_amd.dist) -------------------
     def rows_per_rank(self, world):
         return self.lib.ipc_rows_per_rank(self.N, world)

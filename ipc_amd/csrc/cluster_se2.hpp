@@ -1,0 +1,655 @@
+// General SE(2) cluster solve: odometry chain lo..hi + ANY number of loop edges, one problem at a
+// time, host-driven dog-leg over small grid-wide kernels.  Used by
+//   * the faithful incremental mode  (IPC::agreementCheck, reference src/consensus.cpp:43-75:
+//     cluster of the candidate + every transitively overlapping accepted edge), and
+//   * the final map optimisation     (reference src/simulation.cpp:50-65: optimize(1000) over the
+//     un-scaled odometry + every accepted loop).
+// Same formulation as se2_cell.hpp (chain closed form, G = Gamma_l Phi_j, capacitance system),
+// but the capacitance matrix is (3 nl) x (3 nl) and is factored by dense_chol.hpp; per-edge state lives in HBM arrays instead of registers, loop ranges are handled with prefix
+// sums of Psi_j / w_j, and the dog-leg control flow runs on the host (a few scalars per trial
+// cross PCIe).  This mode is sequential by nature -- it is the reference's algorithm, not the
+// throughput path.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "dense_chol.hpp"
+#include "se2_cell.hpp"
+
+namespace ipc {
+
+struct PoseArr { double *x, *y, *th, *c, *s; };
+
+struct ClusterDev {
+    const double* chain; int estride; int lo; int L; int nl; int ld;   // ld = L + 2 (row length of per-edge arrays)
+    const double* cand; int cstride;
+    const int *lfrom, *lto, *lcand;          // [nl] local pose indices / candidate record index
+    PoseArr X, Xn;                           // [L+1]
+    double *e, *en;                          // [3][ld]  odometry errors (index j = edge j-1 -> j)
+    double *le, *len;                        // [3][nl]  loop errors
+    double *g, *m;                           // [3][ld]
+    double *lg, *lm;                         // [3][nl]
+    double *b, *h;                           // [3][ld]
+    double *ps;                              // [9][ld]  prefix sums of Psi (6) and w (3)
+    double *gam;                             // [9][nl]
+    double *S; int ldS;                      // (NS+1) x NS column major, ldS = NS+1; row NS holds the rhs
+    double *rhs;                             // [NS] solution mu of the capacitance system
+    double *nu;                              // [3][nl]
+    double *nd;                              // [3][ld]  event sums -> n_j
+    double *sc;                              // [3][ld]  scan workspace
+    const int *adj_ptr, *adj_item;           // per pose p: items l*2 + role (0 = from, 1 = to)
+    const int *ev_ptr, *ev_item;             // per index j: items l*2 + kind (0 = start, 1 = end)
+    double* partial;                         // [nblocks][4]
+    double* scal;                            // [8] reduced scalars
+    double* chi_edges;                       // [L + nl] per-edge chi2 (output)
+};
+
+constexpr int kGB = 256;                     // threads per block of the grid kernels
+
+template <int K>
+__device__ __forceinline__ void gk_block_reduce_store(double (&v)[K], double* partial_row)
+{
+    __shared__ double shm[K][kGB];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) shm[k][t] = v[k];
+    __syncthreads();
+    for (int s = kGB / 2; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) shm[k][t] += shm[k][t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) partial_row[k] = shm[k][0];
+    }
+}
+
+// sum of the per-block partials in block order (deterministic) -> scal[off + k]
+__global__ void gk_sum(const double* partial, int nblocks, int K, double* scal, int off)
+{
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double acc = 0.0;
+    for (int bq = 0; bq < nblocks; ++bq) acc += partial[bq * 4 + k];
+    scal[off + k] = acc;
+}
+
+__device__ __forceinline__ Pose2 gk_pose(const PoseArr& A, int p)
+{
+    return Pose2{A.x[p], A.y[p], A.th[p], A.c[p], A.s[p]};
+}
+__device__ __forceinline__ Sym3 gk_sym(const double* base, int stride, int field0, int idx)
+{
+    return load_sym3(base, stride, field0, idx);
+}
+
+// errors + chi2 of the poses Y (trial or committed); edges 1..L then loops
+__global__ void gk_eval(ClusterDev D, PoseArr Y, double* eo, double* leo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        const Pose2 a = gk_pose(Y, i - 1), b = gk_pose(Y, i);
+        double e0, e1, e2;
+        se2_error(a, b, D.chain[(size_t)F_TZX * D.estride + k], D.chain[(size_t)F_TZY * D.estride + k],
+                  D.chain[(size_t)F_CZ * D.estride + k], D.chain[(size_t)F_SZ * D.estride + k],
+                  D.chain[(size_t)F_THZ * D.estride + k], e0, e1, e2);
+        eo[i] = e0; eo[D.ld + i] = e1; eo[2 * D.ld + i] = e2;
+        v[0] = gk_sym(D.chain, D.estride, F_OM, k).quad(e0, e1, e2);
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1, c = D.lcand[l];
+        const Pose2 a = gk_pose(Y, D.lfrom[l]), b = gk_pose(Y, D.lto[l]);
+        double e0, e1, e2;
+        se2_error(a, b, D.cand[(size_t)F_TZX * D.cstride + c], D.cand[(size_t)F_TZY * D.cstride + c],
+                  D.cand[(size_t)F_CZ * D.cstride + c], D.cand[(size_t)F_SZ * D.cstride + c],
+                  D.cand[(size_t)F_THZ * D.cstride + c], e0, e1, e2);
+        leo[l] = e0; leo[D.nl + l] = e1; leo[2 * D.nl + l] = e2;
+        v[0] = gk_sym(D.cand, D.cstride, F_OM, c).quad(e0, e1, e2);
+    }
+    gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
+}
+
+// per-edge chi2 of the committed state (output for the per-edge threshold test)
+__global__ void gk_chi_edges(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        D.chi_edges[i - 1] = gk_sym(D.chain, D.estride, F_OM, k).quad(D.e[i], D.e[D.ld + i], D.e[2 * D.ld + i]);
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1;
+        D.chi_edges[D.L + l] = gk_sym(D.cand, D.cstride, F_OM, D.lcand[l]).quad(D.le[l], D.le[D.nl + l], D.le[2 * D.nl + l]);
+    }
+}
+
+// forces g = (P q_t, q_th), hand-backs m = (g_t, g_th + (J dt).g_t), Gamma_l
+__global__ void gk_force(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
+        double q0, q1, q2;
+        gk_sym(D.chain, D.estride, F_OM, k).mul(D.e[i], D.e[D.ld + i], D.e[2 * D.ld + i], q0, q1, q2);
+        const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
+        const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
+        const double gx = cP * q0 - sP * q1, gy = sP * q0 + cP * q1;
+        const double dx = b.x - a.x, dy = b.y - a.y;
+        D.g[i] = gx; D.g[D.ld + i] = gy; D.g[2 * D.ld + i] = q2;
+        D.m[i] = gx; D.m[D.ld + i] = gy; D.m[2 * D.ld + i] = q2 + (-dy * gx + dx * gy);
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1, c = D.lcand[l];
+        const Pose2 a = gk_pose(D.X, D.lfrom[l]), b = gk_pose(D.X, D.lto[l]);
+        double q0, q1, q2;
+        gk_sym(D.cand, D.cstride, F_OM, c).mul(D.le[l], D.le[D.nl + l], D.le[2 * D.nl + l], q0, q1, q2);
+        const double cz = D.cand[(size_t)F_CZ * D.cstride + c], sz = D.cand[(size_t)F_SZ * D.cstride + c];
+        const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
+        const double gx = cP * q0 - sP * q1, gy = sP * q0 + cP * q1;
+        const double dx = b.x - a.x, dy = b.y - a.y;
+        D.lg[l] = gx; D.lg[D.nl + l] = gy; D.lg[2 * D.nl + l] = q2;
+        D.lm[l] = gx; D.lm[D.nl + l] = gy; D.lm[2 * D.nl + l] = q2 + (-dy * gx + dx * gy);
+        // Gamma_l = sigma [[Lam, Lam K],[0,1]],  Lam = R(-(th_f + thz)),  K = J (t_to - o), o = pose 0
+        const double A = cP, B = sP;          // cos / sin of (th_f + thz)
+        const double Kx = -(b.y - D.X.y[0]), Ky = b.x - D.X.x[0];
+        const double sg = D.lto[l] > D.lfrom[l] ? 1.0 : -1.0;
+        double* G = D.gam;
+        G[0 * D.nl + l] = sg * A;  G[1 * D.nl + l] = sg * B; G[2 * D.nl + l] = sg * (A * Kx + B * Ky);
+        G[3 * D.nl + l] = -sg * B; G[4 * D.nl + l] = sg * A; G[5 * D.nl + l] = sg * (-B * Kx + A * Ky);
+        G[6 * D.nl + l] = 0.0;     G[7 * D.nl + l] = 0.0;    G[8 * D.nl + l] = sg;
+    }
+}
+
+// b_j = m_{j+1} - g_j + loop terms; partial b^T b
+__global__ void gk_b(ClusterDev D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (j >= 1 && j <= D.L) {
+        double b0 = -D.g[j], b1 = -D.g[D.ld + j], b2 = -D.g[2 * D.ld + j];
+        if (j < D.L) { b0 += D.m[j + 1]; b1 += D.m[D.ld + j + 1]; b2 += D.m[2 * D.ld + j + 1]; }
+        for (int q = D.adj_ptr[j]; q < D.adj_ptr[j + 1]; ++q) {
+            const int it = D.adj_item[q], l = it >> 1;
+            if (it & 1) { b0 -= D.lg[l]; b1 -= D.lg[D.nl + l]; b2 -= D.lg[2 * D.nl + l]; }
+            else        { b0 += D.lm[l]; b1 += D.lm[D.nl + l]; b2 += D.lm[2 * D.nl + l]; }
+        }
+        D.b[j] = b0; D.b[D.ld + j] = b1; D.b[2 * D.ld + j] = b2;
+        v[0] = b0 * b0 + b1 * b1 + b2 * b2;
+    }
+    gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
+}
+
+// partial b^T H b = sum_e |J_e b|^2_Om ; also Psi_j / w_j (before the prefix sums)
+__global__ void gk_bHb_psi(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
+        const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
+        const double va0 = i > 1 ? D.b[i - 1] : 0.0, va1 = i > 1 ? D.b[D.ld + i - 1] : 0.0, va2 = i > 1 ? D.b[2 * D.ld + i - 1] : 0.0;
+        double wx, wy, wth;
+        se2_apply_J(a, b, cz, sz, va0, va1, va2, D.b[i], D.b[D.ld + i], D.b[2 * D.ld + i], wx, wy, wth);
+        v[0] = gk_sym(D.chain, D.estride, F_OM, k).quad(wx, wy, wth);
+        // Psi_j = Phi Cov Phi^T, w_j = Phi e_j,  Phi = [[P, -kappa],[0,1]], kappa = J (t_j - o)
+        const Sym3 sg = gk_sym(D.chain, D.estride, F_SG, k);
+        const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
+        const double kx = -(b.y - D.X.y[0]), ky = b.x - D.X.x[0];
+        const double cc = c * c, ss = sn * sn, cs = c * sn;
+        const double C00 = cc * sg.a00 - 2 * cs * sg.a01 + ss * sg.a11;
+        const double C01 = cs * (sg.a00 - sg.a11) + (cc - ss) * sg.a01;
+        const double C11 = ss * sg.a00 + 2 * cs * sg.a01 + cc * sg.a11;
+        const double c0 = c * sg.a02 - sn * sg.a12, c1 = sn * sg.a02 + c * sg.a12;
+        const double sth = sg.a22;
+        const double p02 = c0 - sth * kx, p12 = c1 - sth * ky;
+        D.ps[0 * D.ld + i] = C00 - kx * c0 - kx * p02;
+        D.ps[1 * D.ld + i] = C01 - kx * c1 - ky * p02;
+        D.ps[2 * D.ld + i] = p02;
+        D.ps[3 * D.ld + i] = C11 - ky * c1 - ky * p12;
+        D.ps[4 * D.ld + i] = p12;
+        D.ps[5 * D.ld + i] = sth;
+        const double e0 = D.e[i], e1 = D.e[D.ld + i], e2 = D.e[2 * D.ld + i];
+        D.ps[6 * D.ld + i] = c * e0 - sn * e1 - kx * e2;
+        D.ps[7 * D.ld + i] = sn * e0 + c * e1 - ky * e2;
+        D.ps[8 * D.ld + i] = e2;
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1, c = D.lcand[l];
+        const int f = D.lfrom[l], t = D.lto[l];
+        const Pose2 a = gk_pose(D.X, f), b = gk_pose(D.X, t);
+        const double va0 = f > 0 ? D.b[f] : 0.0, va1 = f > 0 ? D.b[D.ld + f] : 0.0, va2 = f > 0 ? D.b[2 * D.ld + f] : 0.0;
+        const double vb0 = t > 0 ? D.b[t] : 0.0, vb1 = t > 0 ? D.b[D.ld + t] : 0.0, vb2 = t > 0 ? D.b[2 * D.ld + t] : 0.0;
+        double wx, wy, wth;
+        se2_apply_J(a, b, D.cand[(size_t)F_CZ * D.cstride + c], D.cand[(size_t)F_SZ * D.cstride + c], va0, va1, va2,
+                    vb0, vb1, vb2, wx, wy, wth);
+        v[0] = gk_sym(D.cand, D.cstride, F_OM, c).quad(wx, wy, wth);
+    } else if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D.ps[k * D.ld] = 0.0;
+    }
+    gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
+}
+
+// in-place inclusive prefix sums over indices 1..L of K arrays (row length ld), one workgroup
+__global__ __launch_bounds__(1024) void gk_scan(double* arr, int K, int L, int ld)
+{
+    __shared__ double wsum[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int k = 0; k < K; ++k) {
+        double* a = arr + (size_t)k * ld;
+        double carry = 0.0;
+        for (int base = 1; base <= L; base += 1024) {
+            const int i = base + tid;
+            double v = i <= L ? a[i] : 0.0;
+            v = wave_inclusive_scan(v);
+            if (lane == 63) wsum[wave] = v;
+            __syncthreads();
+            double off = carry;
+            for (int w = 0; w < wave; ++w) off += wsum[w];
+            double tot = carry;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            if (i <= L) a[i] = v + off;
+            carry = tot;
+            __syncthreads();
+        }
+    }
+}
+
+// capacitance system: S (lower triangle, column major) and rhs
+__global__ void gk_assemble(ClusterDev D)
+{
+    const int l2 = blockIdx.x * blockDim.x + threadIdx.x;     // column block
+    const int l1 = blockIdx.y;                                 // row block
+    if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
+    const int NS = 3 * D.nl;
+    const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
+    const int lo2 = min(D.lfrom[l2], D.lto[l2]), hi2 = max(D.lfrom[l2], D.lto[l2]);
+    const int a = max(lo1, lo2), bq = min(hi1, hi2);
+    double Mm[6] = {0, 0, 0, 0, 0, 0};
+    if (bq > a) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Mm[k] = D.ps[k * D.ld + bq] - D.ps[k * D.ld + a];
+    }
+    double G1[3][3], G2[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { G1[r][c] = D.gam[(3 * r + c) * D.nl + l1]; G2[r][c] = D.gam[(3 * r + c) * D.nl + l2]; }
+    const double M3[3][3] = {{Mm[0], Mm[1], Mm[2]}, {Mm[1], Mm[3], Mm[4]}, {Mm[2], Mm[4], Mm[5]}};
+    double GM[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) GM[r][c] = G1[r][0] * M3[0][c] + G1[r][1] * M3[1][c] + G1[r][2] * M3[2][c];
+    const Sym3 sgl = gk_sym(D.cand, D.cstride, F_SG, D.lcand[l1]);
+    const double Sg[3][3] = {{sgl.a00, sgl.a01, sgl.a02}, {sgl.a01, sgl.a11, sgl.a12}, {sgl.a02, sgl.a12, sgl.a22}};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = GM[r][0] * G2[c][0] + GM[r][1] * G2[c][1] + GM[r][2] * G2[c][2];
+            if (l1 == l2) t += Sg[r][c];
+            D.S[(size_t)(3 * l2 + c) * D.ldS + (3 * l1 + r)] = t;
+        }
+    if (l1 == l2) {
+        const double W0 = D.ps[6 * D.ld + hi1] - D.ps[6 * D.ld + lo1];
+        const double W1 = D.ps[7 * D.ld + hi1] - D.ps[7 * D.ld + lo1];
+        const double W2 = D.ps[8 * D.ld + hi1] - D.ps[8 * D.ld + lo1];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            D.S[(size_t)(3 * l1 + r) * D.ldS + NS] = D.le[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2);
+    }
+}
+
+// nu_l = Gamma_l^T mu_l
+__global__ void gk_nu(ClusterDev D)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= D.nl) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t += D.gam[(3 * r + c) * D.nl + l] * D.rhs[3 * l + r];
+        D.nu[c * D.nl + l] = t;
+    }
+}
+
+// nd[j] = sum of the events at index j (+nu at the start of a loop range, -nu one past its end)
+__global__ void gk_events(ClusterDev D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > D.L + 1) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (j >= 1) {
+        for (int q = D.ev_ptr[j]; q < D.ev_ptr[j + 1]; ++q) {
+            const int it = D.ev_item[q], l = it >> 1;
+            const double sgn = (it & 1) ? -1.0 : 1.0;
+            a0 += sgn * D.nu[l]; a1 += sgn * D.nu[D.nl + l]; a2 += sgn * D.nu[2 * D.nl + l];
+        }
+    }
+    D.nd[j] = a0; D.nd[D.ld + j] = a1; D.nd[2 * D.ld + j] = a2;
+}
+
+// u_j = -Cov Phi^T n_j - e_j ; rho = (P u_t, u_th): rho_th -> sc[0], rho_t -> sc[1], sc[2]
+__global__ void gk_rho(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 1 || i > D.L) return;
+    const int k = D.lo + i - 1;
+    const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
+    const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
+    const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
+    const double kx = -(b.y - D.X.y[0]), ky = b.x - D.X.x[0];
+    const double n0 = D.nd[i], n1 = D.nd[D.ld + i], n2 = D.nd[2 * D.ld + i];
+    const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
+    double vx, vy, vth;
+    gk_sym(D.chain, D.estride, F_SG, k).mul(wx, wy, wth, vx, vy, vth);
+    const double ux = -vx - D.e[i], uy = -vy - D.e[D.ld + i], uth = -vth - D.e[2 * D.ld + i];
+    D.sc[i] = uth;
+    D.sc[D.ld + i] = c * ux - sn * uy;
+    D.sc[2 * D.ld + i] = sn * ux + c * uy;
+}
+// term = rho_t + J dt h_theta(j-1)  (sc[0] already holds the inclusive theta prefix)
+__global__ void gk_term(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 1 || i > D.L) return;
+    const double thPrev = i > 1 ? D.sc[i - 1] : 0.0;
+    const double dx = D.X.x[i] - D.X.x[i - 1], dy = D.X.y[i] - D.X.y[i - 1];
+    D.sc[D.ld + i] += -dy * thPrev;
+    D.sc[2 * D.ld + i] += dx * thPrev;
+}
+// h = (sc1, sc2, sc0); partial |h|^2, b.h
+__global__ void gk_h(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    if (i >= 1 && i <= D.L) {
+        const double h0 = D.sc[D.ld + i], h1 = D.sc[2 * D.ld + i], h2 = D.sc[i];
+        D.h[i] = h0; D.h[D.ld + i] = h1; D.h[2 * D.ld + i] = h2;
+        v[0] = h0 * h0 + h1 * h1 + h2 * h2;
+        v[1] = D.b[i] * h0 + D.b[D.ld + i] * h1 + D.b[2 * D.ld + i] * h2;
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+// c = hsd.(hgn - hsd), |hgn - hsd|^2 for the dog-leg blend
+__global__ void gk_blend(ClusterDev D, double alpha)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    if (i >= 1 && i <= D.L) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double sk = alpha * D.b[k * D.ld + i], ak = D.h[k * D.ld + i] - sk;
+            v[0] += sk * ak;
+            v[1] += ak * ak;
+        }
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+// trial poses Xn = X (+) (p b + q h); partial "changed" count
+__global__ void gk_update(ClusterDev D, double p, double q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (i == 0) { D.Xn.x[0] = D.X.x[0]; D.Xn.y[0] = D.X.y[0]; D.Xn.th[0] = D.X.th[0]; D.Xn.c[0] = D.X.c[0]; D.Xn.s[0] = D.X.s[0]; }
+    if (i >= 1 && i <= D.L) {
+        const double x = D.X.x[i] + fma(p, D.b[i], q * D.h[i]);
+        const double y = D.X.y[i] + fma(p, D.b[D.ld + i], q * D.h[D.ld + i]);
+        const double th = wrap_pi(D.X.th[i] + fma(p, D.b[2 * D.ld + i], q * D.h[2 * D.ld + i]));
+        double s, c;
+        sincos_pi(th, s, c);
+        D.Xn.x[i] = x; D.Xn.y[i] = y; D.Xn.th[i] = th; D.Xn.c[i] = c; D.Xn.s[i] = s;
+        v[0] = (x != D.X.x[i] || y != D.X.y[i] || th != D.X.th[i]) ? 1.0 : 0.0;
+    }
+    gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
+}
+
+// ------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------
+struct ClusterOut {
+    double max_chi2 = 0.0, chi2_total = 0.0, chi2_initial = 0.0;
+    int iterations = 0, tries = 0, flags = 0, evals = 0;    // flags: 1 terminated, 2 solve failed
+};
+
+class ClusterSolver2 {
+public:
+    ~ClusterSolver2() { release(); }
+
+    // Solve chain lo..hi (records `chain`) + the loops `members` (indices into the candidate
+    // records; ids in from/to are global vertex ids), starting from the poses `src` (global
+    // indexing).  The optimised poses stay in result() (local indexing 0..hi-lo).
+    // chi_host (optional): per-edge chi2, odometry lo..hi-1 first, then the loops in `members` order.
+    hipError_t solve(hipStream_t st, const double* chain, int estride, const double* cand, int cstride,
+                     const PoseArr& src, int lo, int hi, const std::vector<int>& members, const int* from,
+                     const int* to, int iterations, ClusterOut& out, std::vector<double>* chi_host);
+    const PoseArr& result() const { return dev_.X; }
+
+private:
+    ClusterDev dev_{};
+    int capL_ = 0, capNl_ = 0;
+    double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_partial_ = nullptr, *d_scal_ = nullptr;
+    int *d_int_ = nullptr, *d_info_ = nullptr;
+    double* h_scal_ = nullptr;          // pinned [8] + info
+    std::vector<int> h_int_;
+
+    void release()
+    {
+        hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_scal_);
+        hipFree(d_int_); hipFree(d_info_);
+        if (h_scal_) hipHostFree(h_scal_);
+        d_edge_ = d_loop_ = d_S_ = d_partial_ = d_scal_ = nullptr; d_int_ = d_info_ = nullptr; h_scal_ = nullptr;
+        capL_ = capNl_ = 0;
+    }
+    hipError_t ensure(int L, int nl);
+};
+
+#define IPC_CL_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+inline hipError_t ClusterSolver2::ensure(int L, int nl)
+{
+    if (!h_scal_) {
+        IPC_CL_CHK(hipHostMalloc(&h_scal_, sizeof(double) * 16));
+        IPC_CL_CHK(hipMalloc(&d_scal_, sizeof(double) * 16));
+        IPC_CL_CHK(hipMalloc(&d_info_, sizeof(int)));
+    }
+    if (L > capL_ || nl > capNl_) {
+        const int nL = std::max(L, capL_), nN = std::max(nl, capNl_);
+        hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_int_);
+        d_edge_ = d_loop_ = d_S_ = d_partial_ = nullptr; d_int_ = nullptr;
+        capL_ = capNl_ = 0;
+        const size_t ld = (size_t)nL + 2;
+        IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (43 * ld + ld + nN)));
+        IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (27 * (size_t)nN + 8)));
+        IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * (3 * (size_t)nN + 1) * (3 * (size_t)nN)));
+        IPC_CL_CHK(hipMalloc(&d_partial_, sizeof(double) * 4 * ((nL + nN + 1 + kGB) / kGB + 1)));
+        IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * (7 * (size_t)nN + 2 * ld + 8)));
+        capL_ = nL; capNl_ = nN;
+    }
+    return hipSuccess;
+}
+
+inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int estride, const double* cand,
+                                        int cstride, const PoseArr& src, int lo, int hi,
+                                        const std::vector<int>& members, const int* from, const int* to,
+                                        int iterations, ClusterOut& out, std::vector<double>* chi_host)
+{
+    const int L = hi - lo, nl = (int)members.size(), NS = 3 * nl;
+    IPC_CL_CHK(ensure(L, nl));
+    const int ld = L + 2;
+    ClusterDev& D = dev_;
+    D.chain = chain; D.estride = estride; D.lo = lo; D.L = L; D.nl = nl; D.ld = ld;
+    D.cand = cand; D.cstride = cstride;
+    {   // carve the workspaces
+        double* p = d_edge_;
+        auto take = [&](size_t n) { double* q = p; p += n; return q; };
+        D.X = PoseArr{take(ld), take(ld), take(ld), take(ld), take(ld)};
+        D.Xn = PoseArr{take(ld), take(ld), take(ld), take(ld), take(ld)};
+        D.e = take(3 * ld); D.en = take(3 * ld); D.g = take(3 * ld); D.m = take(3 * ld);
+        D.b = take(3 * ld); D.h = take(3 * ld); D.ps = take(9 * ld); D.nd = take(3 * ld); D.sc = take(3 * ld);
+        D.chi_edges = take(ld + nl);
+        double* q = d_loop_;
+        auto takel = [&](size_t n) { double* r = q; q += n; return r; };
+        D.le = takel(3 * nl); D.len = takel(3 * nl); D.lg = takel(3 * nl); D.lm = takel(3 * nl);
+        D.gam = takel(9 * nl); D.nu = takel(3 * nl); D.rhs = takel(3 * nl);
+        D.S = d_S_; D.ldS = NS + 1;
+        D.partial = d_partial_; D.scal = d_scal_;
+    }
+    {   // loop tables: local endpoints, per-pose adjacency, per-index range events
+        h_int_.assign(7 * (size_t)nl + 2 * (size_t)ld + 8, 0);
+        int* lf = h_int_.data();
+        int* lt = lf + nl;
+        int* lc = lt + nl;
+        int* adj_ptr = lc + nl;            // [L+2]
+        int* adj_item = adj_ptr + (L + 2); // [2 nl]
+        int* ev_ptr = adj_item + 2 * nl;   // [L+3]
+        int* ev_item = ev_ptr + (L + 3);   // [2 nl]
+        for (int l = 0; l < nl; ++l) {
+            lf[l] = from[members[l]] - lo; lt[l] = to[members[l]] - lo; lc[l] = members[l];
+            ++adj_ptr[lf[l] + 1]; ++adj_ptr[lt[l] + 1];
+            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
+            ++ev_ptr[a + 1 + 1]; ++ev_ptr[b + 1 + 1];
+        }
+        for (int j = 0; j <= L; ++j) adj_ptr[j + 1] += adj_ptr[j];
+        for (int j = 0; j <= L + 1; ++j) ev_ptr[j + 1] += ev_ptr[j];
+        std::vector<int> ca(adj_ptr, adj_ptr + L + 1), ce(ev_ptr, ev_ptr + L + 2);
+        for (int l = 0; l < nl; ++l) {
+            adj_item[ca[lf[l]]++] = 2 * l;
+            adj_item[ca[lt[l]]++] = 2 * l + 1;
+            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
+            ev_item[ce[a + 1]++] = 2 * l;
+            ev_item[ce[b + 1]++] = 2 * l + 1;
+        }
+        IPC_CL_CHK(hipMemcpyAsync(d_int_, h_int_.data(), sizeof(int) * h_int_.size(), hipMemcpyHostToDevice, st));
+        IPC_CL_CHK(hipStreamSynchronize(st));       // h_int_ is pageable and reused
+        D.lfrom = d_int_; D.lto = d_int_ + nl; D.lcand = d_int_ + 2 * nl;
+        D.adj_ptr = d_int_ + 3 * nl; D.adj_item = D.adj_ptr + (L + 2);
+        D.ev_ptr = D.adj_item + 2 * nl; D.ev_item = D.ev_ptr + (L + 3);
+    }
+    const double* sp[5] = {src.x, src.y, src.th, src.c, src.s};
+    double* xp[5] = {D.X.x, D.X.y, D.X.th, D.X.c, D.X.s};
+    for (int k = 0; k < 5; ++k)
+        IPC_CL_CHK(hipMemcpyAsync(xp[k], sp[k] + lo, sizeof(double) * (L + 1), hipMemcpyDeviceToDevice, st));
+
+    const int nblk = (L + nl + 1 + kGB - 1) / kGB;      // indices 0 .. L+nl
+    const dim3 grid(nblk), block(kGB);
+    auto fetch = [&](int n) -> hipError_t {
+        IPC_CL_CHK(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        IPC_CL_CHK(hipMemcpyAsync(h_scal_ + 12, d_info_, sizeof(int), hipMemcpyDeviceToHost, st));
+        return hipStreamSynchronize(st);
+    };
+    auto evaluate = [&](const PoseArr& Y, double* eo, double* leo, double& chi) -> hipError_t {
+        hipLaunchKernelGGL(gk_eval, grid, block, 0, st, D, Y, eo, leo);
+        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 7);
+        IPC_CL_CHK(fetch(8));
+        chi = h_scal_[7];
+        return hipSuccess;
+    };
+
+    out = ClusterOut{};
+    double currentChi;
+    IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
+    IPC_CL_CHK(evaluate(D.X, D.e, D.le, currentChi));
+    out.chi2_initial = currentChi;
+    double delta = 1e4;
+    const int maxTrials = 100;
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(gk_force, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_b, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 0);
+        hipLaunchKernelGGL(gk_bHb_psi, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 1);
+        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.ps, 9, L, ld);
+        hipLaunchKernelGGL(gk_assemble, dim3((nl + 63) / 64, nl), dim3(64), 0, st, D);
+        IPC_CL_CHK(chol_solve_device(D.S, NS, D.rhs, d_info_, st));
+        hipLaunchKernelGGL(gk_nu, dim3((nl + 63) / 64), dim3(64), 0, st, D);
+        hipLaunchKernelGGL(gk_events, dim3((L + 2 + kGB - 1) / kGB), block, 0, st, D);
+        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.nd, 3, L, ld);
+        hipLaunchKernelGGL(gk_rho, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.sc, 1, L, ld);
+        hipLaunchKernelGGL(gk_term, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.sc + ld, 2, L, ld);
+        hipLaunchKernelGGL(gk_h, grid, block, 0, st, D);
+        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 2, D.scal, 2);
+        IPC_CL_CHK(hipGetLastError());
+        IPC_CL_CHK(fetch(4));
+        int info;
+        std::memcpy(&info, h_scal_ + 12, sizeof(int));
+        if (info != 0) { out.flags |= 2; out.iterations = it + 1; break; }
+        const double bb = h_scal_[0], bHb = h_scal_[1], bh = h_scal_[3], hHh = bh;
+        const double alpha = bb / bHb, hsdNorm = std::sqrt(alpha * alpha * bb), hgnNorm = std::sqrt(h_scal_[2]);
+        bool goodStep = false;
+        int numTries = 0;
+        do {
+            ++numTries;
+            int stepType;
+            double beta = 0.0, sdScale = 0.0;
+            if (hgnNorm < delta) stepType = 0;
+            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
+            else {
+                stepType = 2;
+                hipLaunchKernelGGL(gk_blend, grid, block, 0, st, D, alpha);
+                hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 2, D.scal, 4);
+                IPC_CL_CHK(fetch(6));
+                const double c = h_scal_[4], bma = h_scal_[5], hsdSq = alpha * alpha * bb;
+                if (c <= 0.) beta = (-c + std::sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
+                else beta = (delta * delta - hsdSq) / (c + std::sqrt(c * c + bma * (delta * delta - hsdSq)));
+            }
+            double pcoef, qcoef, hdlNorm;
+            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
+            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
+            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double bhdl = pcoef * bb + qcoef * bh;
+            double linearGain = -1 * hdlHhdl + 2 * bhdl;
+            hipLaunchKernelGGL(gk_update, grid, block, 0, st, D, pcoef, qcoef);
+            hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 6);
+            double newChi;
+            IPC_CL_CHK(evaluate(D.Xn, D.en, D.len, newChi));
+            const bool anyChanged = h_scal_[6] != 0.0;
+            ++out.evals;
+            const double nonLinearGain = currentChi - newChi;
+            if (std::fabs(linearGain) < 1e-12) linearGain = 1e-12;
+            const double rho = nonLinearGain / linearGain;
+            if (rho > 0) {
+                goodStep = true;
+                currentChi = newChi;
+                std::swap(D.X, D.Xn); std::swap(D.e, D.en); std::swap(D.le, D.len);
+            }
+            if (rho > 0.75) delta = std::max(delta, 3 * hdlNorm);
+            else if (rho < 0.25) delta *= 0.5;
+            if (!goodStep) {
+                if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                } else if (stepType == 1 && !anyChanged) {
+                    numTries = maxTrials;
+                }
+            }
+        } while (!goodStep && numTries < maxTrials);
+        out.iterations = it + 1;
+        out.tries += numTries;
+        if (numTries == maxTrials || !goodStep) { out.flags |= 1; break; }
+    }
+    // per-edge chi2 of the committed state
+    hipLaunchKernelGGL(gk_chi_edges, grid, block, 0, st, D);
+    IPC_CL_CHK(hipGetLastError());
+    std::vector<double> local;
+    std::vector<double>& chi = chi_host ? *chi_host : local;
+    chi.resize((size_t)L + nl);
+    IPC_CL_CHK(hipMemcpyAsync(chi.data(), D.chi_edges, sizeof(double) * chi.size(), hipMemcpyDeviceToHost, st));
+    IPC_CL_CHK(hipStreamSynchronize(st));
+    double mx = 0.0;
+    bool nan = false;
+    for (double c : chi) { if (c != c) nan = true; else mx = std::max(mx, c); }
+    out.max_chi2 = nan ? std::nan("") : mx;
+    out.chi2_total = currentChi;
+    return hipSuccess;
+}
+
+}  // namespace ipc

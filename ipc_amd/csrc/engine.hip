@@ -21,6 +21,7 @@
 #include "../../include/ipc_amd.h"
 #include "se2_cell.hpp"
 #include "se3_cell.hpp"
+#include "cluster_se2.hpp"
 
 using namespace ipc;
 
@@ -91,7 +92,8 @@ __device__ __forceinline__ void inv_sym3(const double* a, double* o)
 }
 
 // raw file records -> field-major SE2 records (robustifyVoters: info *= scale)
-__global__ void k_se2_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride)
+__global__ void k_se2_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
+                           double unscale = 1.0)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -104,7 +106,9 @@ __global__ void k_se2_prep(int n, const double* meas, const double* info, double
     rec[(size_t)F_SZ * stride + k] = s;
     rec[(size_t)F_THZ * stride + k] = th;
     double om[6], sg[6];
-    for (int q = 0; q < 6; ++q) om[q] = info[6 * k + q] * scale;
+    // unscale != 1: the harness's final map divides the scaled information by s again
+    // (reference src/simulation.cpp:55-56), i.e. (info * s) / s, not the file value
+    for (int q = 0; q < 6; ++q) om[q] = unscale == 1.0 ? info[6 * k + q] * scale : (info[6 * k + q] * scale) / unscale;
     inv_sym3(om, sg);
     for (int q = 0; q < 6; ++q) {
         rec[(size_t)(F_OM + q) * stride + k] = om[q];
@@ -525,6 +529,13 @@ struct ipc_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false; int last_launches = 0;
     // scratch for ipc_run
     unsigned long long *d_upper = nullptr, *d_bits = nullptr; unsigned char* d_acc = nullptr; size_t run_cap = 0;
+    // incremental mode / final map (SE2)
+    std::vector<double> h_odom_meas, h_odom_info;      // file values, for the un-scaled chain
+    std::vector<int> h_from, h_to, cns;
+    double* d_chain1 = nullptr;                        // chain records with (info * s) / s
+    double* d_open = nullptr;                          // [5][V] open-loop x y th cos sin
+    double* d_cur = nullptr;                           // [5][V] current estimates
+    ClusterSolver2* cluster = nullptr;
 };
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
@@ -580,6 +591,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipStreamSynchronize(h->own_stream));
     HIPCHK(hipFree(d_m));
     HIPCHK(hipFree(d_i));
+    h->h_odom_meas.assign(odom_meas, odom_meas + (size_t)ms * E);
+    h->h_odom_info.assign(odom_info, odom_info + (size_t)is * E);
     *out = h;
     return IPC_OK;
 }
@@ -599,6 +612,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+    hipFree(h->d_chain1); hipFree(h->d_open); hipFree(h->d_cur);
+    delete h->cluster;
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -614,6 +629,10 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     free_candidates(h);
     h->last_cells = 0;
     h->ev_valid = false;
+    h->cns.clear();
+    h->h_from.clear(); h->h_to.clear();
+    if (h->d_cur && h->d_open)
+        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice));
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
@@ -633,6 +652,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     std::iota(h->order.begin(), h->order.end(), 0);
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
     h->N = n;
+    h->h_from = from; h->h_to = to;
     h->cstride = (n + 63) & ~63;
     const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21, nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
     HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * nf * h->cstride));
@@ -899,5 +919,225 @@ extern "C" int ipc_synchronize(ipc_engine_t* h)
     if (!h) return fail(IPC_ERR_ARG, "ipc_synchronize: NULL handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
+    return IPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// faithful incremental mode + final map, SE2
+// ------------------------------------------------------------------------------------------
+__global__ void k_pose5_init(int V, const double* pose0, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const double th = pose0[2 * (size_t)V + i];
+    double s, c;
+    sincos_pi(th, s, c);
+    out[i] = pose0[i]; out[(size_t)V + i] = pose0[(size_t)V + i]; out[2 * (size_t)V + i] = th;
+    out[3 * (size_t)V + i] = c; out[4 * (size_t)V + i] = s;
+}
+
+// propagateCurrentGuess (reference src/consensus_utils.cpp:61-71): v[i] = v[i-1] * z[i-1] for
+// i = start+1 .. V-1.  Sequential compose, one lane.
+__global__ void k_se2_propagate_tail(int V, int start, const double* rec, int stride, double* cur)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double x = cur[start], y = cur[(size_t)V + start], th = cur[2 * (size_t)V + start];
+    double c = cur[3 * (size_t)V + start], s = cur[4 * (size_t)V + start];
+    for (int i = start + 1; i < V; ++i) {
+        const double tx = rec[(size_t)F_TZX * stride + i - 1], ty = rec[(size_t)F_TZY * stride + i - 1];
+        x += c * tx - s * ty;
+        y += s * tx + c * ty;
+        th = normalize_theta(th + rec[(size_t)F_THZ * stride + i - 1]);
+        sincos_pi(th, s, c);
+        cur[i] = x; cur[(size_t)V + i] = y; cur[2 * (size_t)V + i] = th;
+        cur[3 * (size_t)V + i] = c; cur[4 * (size_t)V + i] = s;
+    }
+}
+
+static PoseArr pose_arr(double* base, int V)
+{
+    return PoseArr{base, base + (size_t)V, base + 2 * (size_t)V, base + 3 * (size_t)V, base + 4 * (size_t)V};
+}
+
+static int ensure_incremental(ipc_engine* h, const char* who)
+{
+    if (h->dim != 2) return fail(IPC_ERR_LIMIT, "%s: the incremental / final-map mode is SE2 only in this build", who);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->d_open) {
+        HIPCHK(hipMalloc(&h->d_open, sizeof(double) * 5 * (size_t)h->V));
+        HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 5 * (size_t)h->V));
+        hipLaunchKernelGGL(k_pose5_init, dim3((h->V + 255) / 256), dim3(256), 0, h->own_stream, h->V, h->d_pose0, h->d_open);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice, h->own_stream));
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+    }
+    if (!h->cluster) h->cluster = new ClusterSolver2();
+    return IPC_OK;
+}
+
+static void fill_info(ipc_check_info_t* info, int lo, int hi, int nloops, const ClusterOut& o)
+{
+    if (!info) return;
+    info->lo = lo; info->hi = hi; info->n_cluster_loops = nloops;
+    info->iterations = o.iterations; info->tries = o.tries; info->flags = o.flags;
+    info->max_chi2 = o.max_chi2; info->chi2_total = o.chi2_total; info->chi2_initial = o.chi2_initial;
+}
+
+extern "C" int ipc_incremental_reset(ipc_engine_t* h)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_reset: NULL handle");
+    if (int rc = ensure_incremental(h, "ipc_incremental_reset")) return rc;
+    HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice));
+    h->cns.clear();
+    return IPC_OK;
+}
+
+extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_check_info_t* info)
+{
+    if (!h || !agrees) return fail(IPC_ERR_ARG, "ipc_agreement_check: NULL argument");
+    if (h->N == 0) return fail(IPC_ERR_STATE, "ipc_agreement_check: no candidates set");
+    if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_agreement_check: candidate %d of %d", k, h->N);
+    if (int rc = ensure_incremental(h, "ipc_agreement_check")) return rc;
+    // computeIndependentSubgraph (src/consensus.cpp:124-171): absorb accepted edges whose id interval
+    // overlaps the growing extremes with positive length, until nothing new is found
+    int lo = h->h_lo[k], hi = h->h_hi[k];
+    std::vector<char> inc(h->cns.size(), 0);
+    std::vector<int> members;
+    bool found = true;
+    while (found) {
+        found = false;
+        for (size_t c = 0; c < h->cns.size(); ++c) {
+            if (inc[c]) continue;
+            const int e = h->cns[c];
+            if (std::min(h->h_hi[e], hi) - std::max(h->h_lo[e], lo) <= 0) continue;
+            lo = std::min(lo, h->h_lo[e]); hi = std::max(hi, h->h_hi[e]);
+            inc[c] = 1; found = true;
+            members.push_back(e);
+        }
+    }
+    const bool intersection = !members.empty();                               // :50-52
+    const double th = intersection ? h->prm.slow_reject_th : h->prm.fast_reject_th;
+    int iters = intersection ? h->prm.slow_reject_iter_base : h->prm.fast_reject_iter_base;
+    const int nclu = (int)members.size();
+    members.push_back(k);                                                     // :56
+    if ((hi - lo) + (int)members.size() > 100) iters *= 5;                   // consensus_utils.cpp:12-13
+    ClusterOut o;
+    HIPCHK(h->cluster->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, pose_arr(h->d_cur, h->V),
+                             lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
+    const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
+    if (agree) {                                                              // :69-71
+        const PoseArr& X = h->cluster->result();
+        const double* xs[5] = {X.x, X.y, X.th, X.c, X.s};
+        for (int f = 0; f < 5; ++f)
+            HIPCHK(hipMemcpyAsync(h->d_cur + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1),
+                                  hipMemcpyDeviceToDevice, h->own_stream));
+        if (hi + 1 < h->V)
+            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, h->own_stream, h->V, hi, h->d_chain,
+                               h->estride, h->d_cur);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+        h->cns.push_back(k);
+    }
+    *agrees = agree ? 1 : 0;
+    fill_info(info, lo, hi, nclu, o);
+    return IPC_OK;
+}
+
+extern "C" int ipc_consensus_size(ipc_engine_t* h, int* n)
+{
+    if (!h || !n) return fail(IPC_ERR_ARG, "ipc_consensus_size: NULL argument");
+    *n = (int)h->cns.size();
+    return IPC_OK;
+}
+
+extern "C" int ipc_consensus_set(ipc_engine_t* h, int* out)
+{
+    if (!h || (!out && !h->cns.empty())) return fail(IPC_ERR_ARG, "ipc_consensus_set: NULL argument");
+    std::copy(h->cns.begin(), h->cns.end(), out);
+    return IPC_OK;
+}
+
+extern "C" int ipc_remove_from_consensus(ipc_engine_t* h, int k, int* removed)
+{
+    if (!h || !removed) return fail(IPC_ERR_ARG, "ipc_remove_from_consensus: NULL argument");
+    if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_remove_from_consensus: candidate %d of %d", k, h->N);
+    *removed = 0;
+    for (auto it = h->cns.begin(); it != h->cns.end(); ++it) {
+        if (h->h_lo[*it] != h->h_lo[k] || h->h_hi[*it] != h->h_hi[k]) continue;
+        h->cns.erase(it);
+        *removed = 1;
+        break;
+    }
+    return IPC_OK;
+}
+
+extern "C" int ipc_add_to_consensus(ipc_engine_t* h, int k)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_add_to_consensus: NULL handle");
+    if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_add_to_consensus: candidate %d of %d", k, h->N);
+    for (int e : h->cns)
+        if (h->h_lo[e] == h->h_lo[k] && h->h_hi[e] == h->h_hi[k]) return IPC_OK;
+    h->cns.push_back(k);
+    // cmpEdgesTime (src/utils.cpp:371-377); std::sort leaves ties unspecified, the build keeps them stable
+    std::stable_sort(h->cns.begin(), h->cns.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
+    return IPC_OK;
+}
+
+static int download_poses(ipc_engine* h, const PoseArr& X, int n, double* poses_out)
+{
+    std::vector<double> tmp(3 * (size_t)n);
+    HIPCHK(hipMemcpy(tmp.data(), X.x, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmp.data() + n, X.y, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmp.data() + 2 * (size_t)n, X.th, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        poses_out[3 * (size_t)i] = tmp[i]; poses_out[3 * (size_t)i + 1] = tmp[(size_t)n + i];
+        poses_out[3 * (size_t)i + 2] = tmp[2 * (size_t)n + i];
+    }
+    return IPC_OK;
+}
+
+extern "C" int ipc_current_poses(ipc_engine_t* h, double* poses_out)
+{
+    if (!h || !poses_out) return fail(IPC_ERR_ARG, "ipc_current_poses: NULL argument");
+    if (int rc = ensure_incremental(h, "ipc_current_poses")) return rc;
+    return download_poses(h, pose_arr(h->d_cur, h->V), h->V, poses_out);
+}
+
+extern "C" int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int iterations, double* poses_out,
+                                  ipc_check_info_t* info)
+{
+    if (!h || (h->N > 0 && !accepted)) return fail(IPC_ERR_ARG, "ipc_final_optimize: NULL argument");
+    if (iterations < 0) return fail(IPC_ERR_ARG, "ipc_final_optimize: iterations %d", iterations);
+    if (int rc = ensure_incremental(h, "ipc_final_optimize")) return rc;
+    const int E = h->V - 1;
+    if (!h->d_chain1) {
+        double *d_m = nullptr, *d_i = nullptr;
+        HIPCHK(hipMalloc(&h->d_chain1, sizeof(double) * F_NFIELDS * h->estride));
+        HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * E));
+        HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * E));
+        HIPCHK(hipMemcpy(d_m, h->h_odom_meas.data(), sizeof(double) * 3 * E, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_i, h->h_odom_info.data(), sizeof(double) * 6 * E, hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(h->d_chain1, 0, sizeof(double) * F_NFIELDS * h->estride, h->own_stream));
+        hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
+                           h->prm.s_factor, h->d_chain1, h->estride, h->prm.s_factor);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+        HIPCHK(hipFree(d_m));
+        HIPCHK(hipFree(d_i));
+    }
+    std::vector<int> members;
+    for (int k : h->order) if (accepted[k]) members.push_back(k);
+    if (members.empty()) {
+        // pure odometry: the open-loop guess already has zero error, optimize() leaves it alone
+        ClusterOut o;
+        fill_info(info, 0, h->V - 1, 0, o);
+        if (poses_out) return download_poses(h, pose_arr(h->d_open, h->V), h->V, poses_out);
+        return IPC_OK;
+    }
+    ClusterOut o;
+    HIPCHK(h->cluster->solve(h->own_stream, h->d_chain1, h->estride, h->d_cand, h->cstride, pose_arr(h->d_open, h->V),
+                             0, h->V - 1, members, h->h_from.data(), h->h_to.data(), iterations, o, nullptr));
+    fill_info(info, 0, h->V - 1, (int)members.size(), o);
+    if (poses_out) return download_poses(h, h->cluster->result(), h->V, poses_out);
     return IPC_OK;
 }

@@ -1,0 +1,138 @@
+"""GPU parity of the faithful incremental mode (IPC::agreementCheck, reference
+src/consensus.cpp:43-75) and of the final map (reference src/simulation.cpp:50-65) against the
+CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5      # chi2 tolerance (relative) of BASELINE.json's north star
+
+
+def _engine(g, **kw):
+    from ipc_amd.consensus import IPC, Config
+    cfg = Config(**kw)
+    return IPC(g, cfg, device=0), cfg
+
+
+def _oracle_inc(O, g, cfg):
+    return O.IncrementalIPC(2, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th,
+                            cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base,
+                            g.loop_ids, g.loop_meas, g.loop_info)
+
+
+def _run_both(O, g, eng, cfg):
+    inc = _oracle_inc(O, g, cfg)
+    order = eng.candidate_order()
+    eng.reset()
+    worst = 0.0
+    for k in order:
+        ok_ref, ref = inc.agreement_check(k)
+        ok, info = eng.agreementCheck(k, with_info=True)
+        assert (info.lo, info.hi, info.n_cluster_loops) == (ref["lo"], ref["hi"], ref["cluster"]), (k, ref)
+        assert ok == ok_ref, (k, ref, info.max_chi2)
+        err = abs(info.max_chi2 - ref["max_chi2"]) / max(abs(ref["max_chi2"]), 1e-12)
+        worst = max(worst, err)
+        assert err <= REL, (k, ref, info.max_chi2)
+        # (the iteration at which the dog-leg gives up near convergence is round-off driven, so
+        # the counts are not compared)
+    assert np.array_equal(eng.getMaxConsensusSet(), inc.consensus())
+    ref_poses = inc.poses()
+    got = eng.current_poses()
+    assert np.allclose(got[:, :2], ref_poses[:, :2], rtol=0, atol=1e-6)
+    dth = np.angle(np.exp(1j * (got[:, 2] - ref_poses[:, 2])))
+    assert np.abs(dth).max() <= 1e-7
+    return worst, inc
+
+
+def test_incremental_small_step_by_step(oracle):
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth.small_se2(), 6, seed=3)
+    eng, cfg = _engine(g)
+    _run_both(oracle, g, eng, cfg)
+
+
+@pytest.mark.parametrize("seed", [5, 11])
+def test_incremental_medium_clusters(oracle, seed):
+    """3 laps: clusters absorb tens of accepted loops (capacitance systems up to ~60 unknowns and
+    the x5 iteration rule)."""
+    from ipc_amd import synth
+    g = synth._se2_graph(400, 24, seed=70 + seed, laps=3.0, name="inc")
+    g = synth.inject_outliers(g, 16, seed=seed)
+    eng, cfg = _engine(g)
+    _, inc = _run_both(oracle, g, eng, cfg)
+    assert len(inc.consensus()) >= 10
+
+
+def test_consensus_set_editing(oracle):
+    """removeEdgeFromCnS / addEdgeToCnS (reference src/consensus.cpp:77-119)."""
+    from ipc_amd import synth
+    g = synth.small_se2()
+    eng, cfg = _engine(g)
+    order = eng.candidate_order()
+    eng.reset()
+    for k in order:
+        eng.agreementCheck(k)
+    cs = list(eng.getMaxConsensusSet())
+    assert len(cs) >= 2
+    k = cs[0]
+    assert eng.removeEdgeFromCnS(k) is True
+    assert list(eng.getMaxConsensusSet()) == cs[1:]
+    assert eng.removeEdgeFromCnS(k) is False
+    eng.addEdgeToCnS(k)
+    after = list(eng.getMaxConsensusSet())
+    assert sorted(after) == sorted(cs)
+    hi = np.maximum(g.loop_ids[:, 0], g.loop_ids[:, 1])
+    assert list(hi[after]) == sorted(hi[after])            # cmpEdgesTime order
+    eng.addEdgeToCnS(k)                                     # same vertex pair: no duplicate
+    assert list(eng.getMaxConsensusSet()) == after
+
+
+def _final_reference(O, g, cfg, acc, iter_base):
+    s = cfg.s_factor
+    info = (np.asarray(g.odom_info) * s) / s                # setInformation(information()/s) after *s
+    poses = O.propagate(2, g.odom_meas)
+    order = O.candidate_order(g.loop_ids)
+    sel = [k for k in order if acc[k]]
+    return O.solve_cell(2, g.odom_meas, info, 1.0, poses, 0, g.V - 1, g.loop_ids[sel], g.loop_meas[sel],
+                        g.loop_info[sel], iter_base, want_poses=True)
+
+
+@pytest.mark.parametrize("which", ["small", "laps"])
+def test_final_map_matches_oracle(oracle, which):
+    from ipc_amd import synth
+    if which == "small":
+        g = synth.inject_outliers(synth.small_se2(), 6, seed=3)
+    else:
+        g = synth.inject_outliers(synth._se2_graph(400, 24, seed=81, laps=3.0, name="fin"), 10, seed=2)
+    eng, cfg = _engine(g)
+    _, acc = eng.run()
+    assert acc.sum() >= 2
+    n_edges = (g.V - 1) + int(acc.sum())
+    iters = 1000
+    # the oracle's cell solve applies the reference's x5 rule to iter_base when #edges > 100
+    base = iters // 5 if n_edges > 100 else iters
+    ref = _final_reference(oracle, g, cfg, acc, base)
+    poses, info = eng.final_optimize(acc, iterations=iters)
+    assert abs(info.chi2_total - ref["chi2_final"]) <= REL * max(ref["chi2_final"], 1e-12)
+    assert abs(info.max_chi2 - ref["max_chi2"]) <= REL * max(ref["max_chi2"], 1e-12)
+    assert np.allclose(poses[:, :2], ref["poses"][:, :2], rtol=0, atol=1e-6)
+    dth = np.angle(np.exp(1j * (poses[:, 2] - ref["poses"][:, 2])))
+    assert np.abs(dth).max() <= 1e-7
+
+
+def test_final_map_without_loops_is_open_loop(oracle):
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth.small_se2(), 4, seed=9)
+    eng, _ = _engine(g)
+    poses, info = eng.final_optimize(np.zeros(g.N, dtype=np.uint8))
+    assert np.allclose(poses, eng.initial_poses(), rtol=0, atol=0)
+    assert info.chi2_total == 0.0
+
+
+def test_incremental_is_se2_only_for_now():
+    from ipc_amd import capi, synth
+    g = synth.small_se3()
+    eng, _ = _engine(g, s_factor=50.0)
+    with pytest.raises(capi.IpcError, match="SE2 only"):
+        eng.reset()
