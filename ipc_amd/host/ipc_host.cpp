@@ -194,6 +194,62 @@ std::vector<uint8_t> IPC::agreementCheckAll(const std::vector<Edge>& cands)
     return acc;
 }
 
+void IPC::setCandidates(const std::vector<Edge>& cands)
+{
+    const int N = (int)cands.size();
+    std::vector<int> ids;
+    std::vector<double> meas, info;
+    for (const Edge& e : cands) {
+        ids.push_back(e.from);
+        ids.push_back(e.to);
+        meas.insert(meas.end(), e.meas.begin(), e.meas.end());
+        info.insert(info.end(), e.info.begin(), e.info.end());
+    }
+    check(ipc_set_candidates(_h, N, ids.data(), meas.data(), info.data()));
+    _order.assign(N, 0);
+    _max_consensus_set.clear();
+    if (N) check(ipc_candidate_order(_h, _order.data()));
+}
+
+void IPC::refreshConsensus()
+{
+    int n = 0;
+    check(ipc_consensus_size(_h, &n));
+    _max_consensus_set.assign(n, 0);
+    if (n) check(ipc_consensus_set(_h, _max_consensus_set.data()));
+}
+
+bool IPC::agreementCheck(int k)
+{
+    int ok = 0;
+    check(ipc_agreement_check(_h, k, &ok, nullptr));
+    if (ok) refreshConsensus();
+    return ok != 0;
+}
+
+bool IPC::removeEdgeFromCnS(int k)
+{
+    int removed = 0;
+    check(ipc_remove_from_consensus(_h, k, &removed));
+    refreshConsensus();
+    return removed != 0;
+}
+
+void IPC::addEdgeToCnS(int k)
+{
+    check(ipc_add_to_consensus(_h, k));
+    refreshConsensus();
+}
+
+std::vector<double> IPC::finalMap(const std::vector<uint8_t>& accepted, int iterations, double* chi2_out)
+{
+    std::vector<double> out((size_t)_V * 3);
+    ipc_check_info_t info{};
+    check(ipc_final_optimize(_h, accepted.data(), iterations, out.data(), &info));
+    if (chi2_out) *chi2_out = info.chi2_total;
+    return out;
+}
+
 std::vector<double> IPC::initialPoses() const
 {
     std::vector<double> out((size_t)_V * (_dim == 2 ? 3 : 12));
@@ -236,8 +292,17 @@ SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph&
     IPC ipc(g, odom, cfg, device);
     std::cout << "Starting simulation of incremental dataset -> Displaying relative status : " << std::endl;
     std::cout << "S = " << cfg.s_factor << " | TH = " << cfg.fast_reject_th << std::endl;
+    const char* mode_env = std::getenv("IPC_AMD_MODE");
+    const bool incremental = mode_env && std::string(mode_env) == "incremental";
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint8_t> bucket = ipc.agreementCheckAll(loops);
+    std::vector<uint8_t> bucket;
+    if (incremental) {                                                            // simulation.cpp:34-47
+        ipc.setCandidates(loops);
+        bucket.assign(tot, 0);
+        for (int k : ipc.order()) bucket[k] = ipc.agreementCheck(k) ? 1 : 0;
+    } else {
+        bucket = ipc.agreementCheckAll(loops);
+    }
     auto t1 = std::chrono::steady_clock::now();
     r.total_time = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() / 1000000.0;
     r.avg_time = tot ? r.total_time / tot : 0.0;
@@ -257,10 +322,10 @@ SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph&
     std::cout << "Precision = " << r.precision << std::endl;
     std::cout << "Recall = " << r.recall << std::endl;
 
-    // Trajectory file.  NOTE (not built yet): the reference writes the
-    // poses after a final optimize(1000) over odometry/s + accepted loops (simulation.cpp:50-65);
-    // this build writes the open-loop (propagateGuess) poses.
-    const std::vector<double> poses = ipc.initialPoses();
+    // Trajectory file: the poses after the final optimize(1000) over odometry/s + accepted loops
+    // (simulation.cpp:50-65).  SE3 (final map not built yet) writes the
+    // open-loop (propagateGuess) poses.
+    const std::vector<double> poses = g.dim == 2 ? ipc.finalMap(bucket, 1000, &r.final_chi2) : ipc.initialPoses();
     const int ps = g.dim == 2 ? 3 : 12;
     std::ofstream outfile(cfg.output.c_str());
     for (int i = 0; i < ipc.numVertices(); ++i) write_pose(outfile, g.dim, &poses[(size_t)i * ps]);

@@ -62,6 +62,17 @@ public:
     // Batched form of the per-candidate agreementCheck loop (src/simulation.cpp:34-47): returns,
     // per candidate (file order), whether it is in the consensus set.
     std::vector<uint8_t> agreementCheckAll(const std::vector<Edge>& candidates);
+    // The reference's own per-candidate interface (faithful incremental mode, SE2):
+    // setCandidates uploads the list once, then agreementCheck(k) is IPC::agreementCheck
+    // (src/consensus.cpp:43-75) for candidate k (index into that list).
+    void setCandidates(const std::vector<Edge>& candidates);
+    bool agreementCheck(int k);
+    bool removeEdgeFromCnS(int k);                      // src/consensus.cpp:77-96
+    void addEdgeToCnS(int k);                           // src/consensus.cpp:98-119
+    // Final map of the harness (src/simulation.cpp:50-65): optimize(iterations) over odometry with
+    // its information back to (info*s)/s plus the accepted candidates; SE2 [V][3].
+    std::vector<double> finalMap(const std::vector<uint8_t>& accepted, int iterations = 1000,
+                                 double* chi2_out = nullptr);
     // candidate indices in acceptance order (reference getMaxConsensusSet, consensus.hpp:16)
     const std::vector<int>& getMaxConsensusSet() const { return _max_consensus_set; }
     // cmpTime processing order of the last candidate list
@@ -71,6 +82,7 @@ public:
     int numVertices() const { return _V; }
 
 private:
+    void refreshConsensus();
     ipc_engine_t* _h = nullptr;
     int _dim = 0, _V = 0;
     std::vector<int> _max_consensus_set, _order;
@@ -81,11 +93,15 @@ struct SimulationResult {
     float precision = 0, recall = 0;
     double total_time = 0, avg_time = 0;
     int consensus_size = 0;
+    double final_chi2 = 0;           // chi2 of the final map (the reference never prints it)
 };
 
 // The harness: labels the first cfg.canonic_inliers loops as inliers (src/simulation.cpp:24-25),
-// runs the consensus, prints the reference's console lines, writes cfg.output (trajectory) and
-// "<output minus 3 chars>PR" (src/simulation.cpp:91-105).
+// runs the consensus, prints the reference's console lines, writes cfg.output (trajectory after
+// the final map optimisation for SE2; open-loop poses for SE3) and "<output minus 3 chars>PR"
+// (src/simulation.cpp:91-105).  Environment IPC_AMD_MODE selects the consensus formulation:
+// "matrix" (default: batched consistency matrix + set-max) or "incremental" (the reference's
+// per-candidate agreementCheck loop on the GPU, SE2 only).
 SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph& g, const std::vector<Edge>& odom,
                                              const std::vector<Edge>& loops, int device = 0);
 

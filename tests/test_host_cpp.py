@@ -81,5 +81,35 @@ def test_tester_outputs_match_python_path(built, tmp_path, dim):
     assert ("Size of MAX consistent set = %d" % int(acc.sum())) in r.stdout
     traj = np.loadtxt(str(tmp_path / "res.txt"))
     assert traj.shape[1] == (3 if dim == 2 else 7)
-    # open-loop poses (documented N2 gap): first pose is the origin
     assert np.allclose(traj[0][:3], 0)
+    if dim == 2:
+        # the trajectory is the final map (reference src/simulation.cpp:50-65,91-98); the file
+        # carries operator<<'s 6 significant digits
+        from ipc_amd import graphio
+        from ipc_amd.consensus import IPC, Config
+        g = graphio.read_g2o(vals["dataset"])
+        eng = IPC(g, Config(vals["fth"], 50, vals["sth"], 100, vals["s"]))
+        poses, _ = eng.final_optimize(acc)
+        assert np.allclose(traj, poses, rtol=2e-5, atol=2e-5)
+        assert not np.allclose(traj, eng.initial_poses(), atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_tester_incremental_mode_matches_python_path(built, tmp_path):
+    """IPC_AMD_MODE=incremental runs the reference's per-candidate loop (src/simulation.cpp:34-47)."""
+    from ipc_amd import graphio
+    from ipc_amd.consensus import IPC, Config
+    cfg, vals = _write_cfg(tmp_path, 2)
+    env = dict(os.environ, IPC_AMD_MODE="incremental")
+    r = subprocess.run([built[2], "-c", cfg], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    g = graphio.read_g2o(vals["dataset"])
+    eng = IPC(g, Config(vals["fth"], 50, vals["sth"], 100, vals["s"]))
+    eng.reset()
+    acc = np.zeros(g.N, dtype=np.uint8)
+    for k in eng.candidate_order():
+        acc[k] = eng.agreementCheck(k)
+    assert ("Size of MAX consistent set = %d" % int(acc.sum())) in r.stdout
+    traj = np.loadtxt(str(tmp_path / "res.txt"))
+    poses, _ = eng.final_optimize(acc)
+    assert np.allclose(traj, poses, rtol=2e-5, atol=2e-5)
