@@ -1,0 +1,53 @@
+// Launch interface of the cell-solver kernels.  The kernels are heavily templated, so they live
+// in their own translation units (se2_block.hip, se2_wave.hip, se3_block.hip) that are compiled
+// in parallel and linked into libipc_amd.so; engine.hip only sees these prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "se2_cell.hpp"
+#include "se3_cell.hpp"
+
+namespace ipc {
+
+struct CellOut {
+    double* max_chi2;
+    double* chi2_total;
+    int4* meta;               // iterations, tries, flags, error evaluations
+};
+
+// ---- block kernels: one workgroup of W waves per cell, M poses per lane; capacity 64*W*M ----
+struct Variant { int W, M; };
+static const Variant kVariants[] = {
+    // M = 1
+    {1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1}, {10, 1}, {12, 1}, {14, 1}, {16, 1},
+    // M = 2
+    {4, 2}, {5, 2}, {6, 2}, {7, 2}, {8, 2}, {10, 2}, {12, 2}, {16, 2},
+    // M = 3
+    {5, 3}, {6, 3}, {7, 3}, {8, 3},
+    // M = 4 and longer chains
+    {4, 4}, {6, 4}, {8, 4}, {16, 4}, {16, 8}, {16, 16},
+    // two waves per cell, two cells per CU
+    {2, 3}, {2, 4}, {2, 5}, {2, 6},
+    // three / four fat waves per cell
+    {3, 4}, {3, 5}, {3, 6}, {4, 3}, {4, 5},
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4} };
+constexpr int kNumVariants3 = sizeof(kVariants3) / sizeof(kVariants3[0]);
+
+hipError_t launch_se2_block(int nl, int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,
+                            SolveParams prm, CellOut out);
+hipError_t launch_se3_block(int nl, int variant, int n, hipStream_t st, const Se3View& P, const int2* cells,
+                            SolveParams prm, CellOut out);
+
+// ---- wave kernels (SE2): one wave per cell, M consecutive poses per lane; capacity 64*M ----
+static const int kWaveM[] = {1, 3, 5};        // larger M spill heavily with this compiler (state + temporaries > 512 VGPRs)
+constexpr int kNumWaveM = sizeof(kWaveM) / sizeof(kWaveM[0]);
+constexpr int kWaveVariantBase = 100;         // plan variant id of the wave kernel with M poses per lane = base + M
+
+// counter: one zeroed unsigned in HBM (work queue of the launch); n_cu: workgroups to launch.
+// The chain window [0, V-1) is staged in LDS when it fits, else the constants are read from L2.
+hipError_t launch_se2_wave(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
+                           SolveParams prm, CellOut out, unsigned* counter, int n_cu);
+
+}  // namespace ipc

@@ -19,8 +19,7 @@
 #include <vector>
 
 #include "../../include/ipc_amd.h"
-#include "se2_cell.hpp"
-#include "se3_cell.hpp"
+#include "cell_kernels.hpp"
 #include "cluster_se2.hpp"
 
 using namespace ipc;
@@ -52,18 +51,6 @@ extern "C" const char* ipc_last_error(void) { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------
 // kernel variants: (threads per cell, poses per thread); capacity = T*M poses
 // ------------------------------------------------------------------------------------------
-struct Variant { int W, M; };                   // waves per cell, poses per lane
-static const Variant kVariants[] = {
-    // M = 1
-    {1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1}, {10, 1}, {12, 1}, {14, 1}, {16, 1},
-    // M = 2
-    {4, 2}, {5, 2}, {6, 2}, {7, 2}, {8, 2}, {10, 2}, {12, 2}, {16, 2},
-    // M = 3
-    {5, 3}, {6, 3}, {7, 3}, {8, 3},
-    // M = 4 and longer chains
-    {4, 4}, {6, 4}, {8, 4}, {16, 4}, {16, 8}, {16, 16},
-};
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kMaxBins = 32;
 struct BinCaps { int n; int cap[kMaxBins]; };
 
@@ -243,143 +230,6 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
 }
 
 // ------------------------------------------------------------------------------------------
-// the hot kernel
-// ------------------------------------------------------------------------------------------
-struct CellOut {
-    double* max_chi2;
-    double* chi2_total;
-    int4* meta;               // iterations, tries, flags, error evaluations
-};
-
-// M == 1 variants are held to 128 VGPRs (4 waves per SIMD => 16 waves per CU: two 8-wave cells
-// or four 4-wave cells in flight per CU, so one cell's barrier waits hide behind another's work)
-#ifndef IPC_MINW
-#define IPC_MINW 1
-#endif
-template <int W, int M, int NL>
-__global__ __launch_bounds__(64 * W, (M == 1 ? IPC_MINW : 1)) void se2_cells_kernel(Se2View P, const int2* cells, int ncells,
-                                                           SolveParams prm, CellOut out)
-{
-    __shared__ Se2Shared<W, M, NL> sh;
-    const int cell = blockIdx.x;
-    if (cell >= ncells) return;
-    const int2 cc = cells[cell];
-    int cand[2] = {cc.x, cc.y};
-    int lo = min(P.cand_from[cc.x], P.cand_to[cc.x]), hi = max(P.cand_from[cc.x], P.cand_to[cc.x]);
-    if (NL == 2) {
-        lo = min(lo, min(P.cand_from[cc.y], P.cand_to[cc.y]));
-        hi = max(hi, max(P.cand_from[cc.y], P.cand_to[cc.y]));
-    }
-    const int L = hi - lo;
-    const int base = NL == 1 ? prm.fast_iter : prm.slow_iter;
-    const int iterations = (L + NL > 100) ? base * 5 : base;       // consensus_utils.cpp:12-13
-    CellResult r;
-    se2_solve_cell<W, M, NL>(P, lo, L, cand, iterations, sh, r);
-    if (threadIdx.x == 0) {
-        out.max_chi2[cell] = r.max_chi2;
-        out.chi2_total[cell] = r.chi2_total;
-        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, r.evals);
-    }
-}
-
-template <int NL>
-static hipError_t launch_se2(int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,
-                             SolveParams prm, CellOut out)
-{
-#define IPC_CASE(idx, WW, MM)                                                                     \
-    case idx:                                                                                     \
-        hipLaunchKernelGGL((se2_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
-        break;
-    switch (variant) {
-        IPC_CASE(0, 1, 1)
-        IPC_CASE(1, 2, 1)
-        IPC_CASE(2, 3, 1)
-        IPC_CASE(3, 4, 1)
-        IPC_CASE(4, 5, 1)
-        IPC_CASE(5, 6, 1)
-        IPC_CASE(6, 7, 1)
-        IPC_CASE(7, 8, 1)
-        IPC_CASE(8, 10, 1)
-        IPC_CASE(9, 12, 1)
-        IPC_CASE(10, 14, 1)
-        IPC_CASE(11, 16, 1)
-        IPC_CASE(12, 4, 2)
-        IPC_CASE(13, 5, 2)
-        IPC_CASE(14, 6, 2)
-        IPC_CASE(15, 7, 2)
-        IPC_CASE(16, 8, 2)
-        IPC_CASE(17, 10, 2)
-        IPC_CASE(18, 12, 2)
-        IPC_CASE(19, 16, 2)
-        IPC_CASE(20, 5, 3)
-        IPC_CASE(21, 6, 3)
-        IPC_CASE(22, 7, 3)
-        IPC_CASE(23, 8, 3)
-        IPC_CASE(24, 4, 4)
-        IPC_CASE(25, 6, 4)
-        IPC_CASE(26, 8, 4)
-        IPC_CASE(27, 16, 4)
-        IPC_CASE(28, 16, 8)
-        IPC_CASE(29, 16, 16)
-        default: return hipErrorInvalidValue;
-    }
-#undef IPC_CASE
-    return hipGetLastError();
-}
-
-// ---- SE3 cell kernel: same contract; variants kept few (the code is large) ----
-template <int W, int M, int NL>
-__global__ __launch_bounds__(64 * W) void se3_cells_kernel(Se3View P, const int2* cells, int ncells,
-                                                           SolveParams prm, CellOut out)
-{
-    __shared__ Se3Shared<W, M, NL> sh;
-    const int cell = blockIdx.x;
-    if (cell >= ncells) return;
-    const int2 cc = cells[cell];
-    int cand[2] = {cc.x, cc.y};
-    int lo = min(P.cand_from[cc.x], P.cand_to[cc.x]), hi = max(P.cand_from[cc.x], P.cand_to[cc.x]);
-    if (NL == 2) {
-        lo = min(lo, min(P.cand_from[cc.y], P.cand_to[cc.y]));
-        hi = max(hi, max(P.cand_from[cc.y], P.cand_to[cc.y]));
-    }
-    const int L = hi - lo;
-    const int base = NL == 1 ? prm.fast_iter : prm.slow_iter;
-    const int iterations = (L + NL > 100) ? base * 5 : base;       // consensus_utils.cpp:12-13
-    CellResult3 r;
-    se3_solve_cell<W, M, NL>(P, lo, L, cand, iterations, sh, r);
-    if (threadIdx.x == 0) {
-        out.max_chi2[cell] = r.max_chi2;
-        out.chi2_total[cell] = r.chi2_total;
-        out.meta[cell] = make_int4(r.iterations, r.tries, r.flags, r.evals);
-    }
-}
-
-static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4} };
-constexpr int kNumVariants3 = sizeof(kVariants3) / sizeof(kVariants3[0]);
-
-template <int NL>
-static hipError_t launch_se3(int variant, int n, hipStream_t st, const Se3View& P, const int2* cells,
-                             SolveParams prm, CellOut out)
-{
-#define IPC_CASE3(idx, WW, MM)                                                                    \
-    case idx:                                                                                     \
-        hipLaunchKernelGGL((se3_cells_kernel<WW, MM, NL>), dim3(n), dim3(64 * WW), 0, st, P, cells, n, prm, out); \
-        break;
-    switch (variant) {
-        IPC_CASE3(0, 1, 1)
-        IPC_CASE3(1, 2, 1)
-        IPC_CASE3(2, 4, 1)
-        IPC_CASE3(3, 8, 1)
-        IPC_CASE3(4, 16, 1)
-        IPC_CASE3(5, 16, 2)
-        IPC_CASE3(6, 16, 4)
-        default: return hipErrorInvalidValue;
-    }
-#undef IPC_CASE3
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // results -> bits
 // ------------------------------------------------------------------------------------------
 __global__ void k_scatter_bits(int ncells, const int2* cells, const double* chi, double fast_th,
@@ -474,10 +324,11 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // engine
 // ------------------------------------------------------------------------------------------
 // Chain-length bins: each bin is served by one (W, M) kernel variant.  The policy string
-// (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens; a cell goes to
-// the listed variant of smallest capacity 64*W*M that holds it.
+// (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens (block kernel, W
+// waves per cell, M poses per lane) or "wM" tokens (SE2 wave kernel, one wave per cell, M poses
+// per lane); a cell goes to the listed variant of smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
-static const char* kDefaultPolicy = "1x1,2x1,3x1,4x1,5x1,6x1,7x1,8x1,5x2,6x2,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "w1,w3,w5,2x3,2x4,2x5,2x6,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
@@ -491,10 +342,16 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
         size_t e = pol.find(',', pos);
         if (e == std::string::npos) e = pol.size();
         int w = 0, m = 0;
-        if (sscanf(pol.substr(pos, e - pos).c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
+        const std::string tok = pol.substr(pos, e - pos);
         int v = -1;
-        for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
-        if (v < 0) { err = "IPC_SE*_POLICY names a variant that is not compiled: " + pol.substr(pos, e - pos); return false; }
+        if (dim == 2 && sscanf(tok.c_str(), "w%d", &m) == 1) {          // wave kernel, M poses per lane
+            w = 1;
+            for (int k = 0; k < kNumWaveM; ++k) if (kWaveM[k] == m) v = kWaveVariantBase + m;
+        } else {
+            if (sscanf(tok.c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
+            for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
+        }
+        if (v < 0) { err = "IPC_SE*_POLICY names a variant that is not compiled: " + tok; return false; }
         items.push_back({64 * w * m, v});
         pos = e + 1;
     }
@@ -523,6 +380,8 @@ struct ipc_engine {
     // plan / results of the last solve
     unsigned* d_counters = nullptr;   // [2*(kMaxBins+1)]
     unsigned* d_offsets = nullptr;
+    unsigned* d_wave_ctr = nullptr;   // work-queue heads of the wave-kernel launches, one per (nl, bin)
+    int n_cu = 256;
     int2* d_cells = nullptr; size_t cells_cap = 0;
     double *d_chi = nullptr, *d_chitot = nullptr; int4* d_meta = nullptr;
     int last_cells = 0;
@@ -566,16 +425,22 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * nf * h->estride));
+    HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * (nf * (size_t)h->estride + 64)));   // + read-ahead padding
     HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * ps * (size_t)n_vertices));
     HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1)));
     HIPCHK(hipMalloc(&h->d_offsets, sizeof(unsigned) * 2 * (kMaxBins + 1)));
+    HIPCHK(hipMalloc(&h->d_wave_ctr, sizeof(unsigned) * 2 * (kMaxBins + 1)));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     double *d_m = nullptr, *d_i = nullptr;
     HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * E));
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * E));
     HIPCHK(hipMemcpy(d_m, odom_meas, sizeof(double) * ms * E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_i, odom_info, sizeof(double) * is * E, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * nf * h->estride, h->own_stream));
+    HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * (nf * (size_t)h->estride + 64), h->own_stream));
     if (dim == 2) {
         hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
                            params->s_factor, h->d_chain, h->estride);
@@ -609,7 +474,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
     free_candidates(h);
-    hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets);
+    hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
     hipFree(h->d_chain1); hipFree(h->d_open); hipFree(h->d_cur);
@@ -773,6 +638,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     const Se3View P3 = make_view3(h);
     const SolveParams sp{h->prm.fast_reject_iter_base, h->prm.slow_reject_iter_base};
     int launches = 0;
+    HIPCHK(hipMemsetAsync(h->d_wave_ctr, 0, sizeof(unsigned) * NS, st));
     HIPCHK(hipEventRecord(h->ev0, st));
     for (int b = nb - 1; b >= 0; --b) {
         for (int nl = 2; nl >= 1; --nl) {
@@ -782,11 +648,12 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             const int var = h->plan.variant[b];
             hipError_t e;
             if (h->dim == 2)
-                e = nl == 1 ? launch_se2<1>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out)
-                            : launch_se2<2>(var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+                e = var >= kWaveVariantBase
+                        ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                                          h->d_wave_ctr + s, h->n_cu)
+                        : launch_se2_block(nl, var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
             else
-                e = nl == 1 ? launch_se3<1>(var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out)
-                            : launch_se3<2>(var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out);
+                e = launch_se3_block(nl, var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }

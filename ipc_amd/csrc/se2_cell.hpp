@@ -268,7 +268,10 @@ struct Se2Cap {
     static constexpr int CAP = 64 * W * M;
     // all 17 fields up to 1024 poses; up to 1536 poses only the 11 fields of the residual pass
     // (measurement + Omega), Sigma then stays an L2 read (used twice per outer iteration)
-    static constexpr int NSTAGED = CAP <= 1024 ? (int)F_NFIELDS : (CAP <= 1536 ? (int)F_SG : 0);
+    // two-wave variants (W == 2) are meant to run two cells per CU (one wave per SIMD, 512 VGPRs
+    // each), so they only take half of the LDS: the 11 residual-pass fields up to 768 poses
+    static constexpr int NSTAGED = W == 2 ? (CAP <= 512 ? (int)F_NFIELDS : (CAP <= 768 ? (int)F_SG : 0))
+                                          : (CAP <= 1024 ? (int)F_NFIELDS : (CAP <= 1536 ? (int)F_SG : 0));
     static constexpr int ROWS = NSTAGED > 0 ? CAP : 1;
     static constexpr int FROWS = NSTAGED > 0 ? NSTAGED : 1;
 };

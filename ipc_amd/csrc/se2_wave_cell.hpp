@@ -1,0 +1,666 @@
+// SE(2) cell solver, one WAVE per cell (the variant for chains up to ~64 * 13 poses).
+//
+// The block kernel (se2_cell.hpp) spreads one chain over W waves and pays a workgroup barrier
+// plus an LDS round trip for every reduction / scan / neighbour hand-off; its phases are
+// dominated by those fixed costs, and with one cell resident per CU the other SIMDs idle while
+// wave 0 solves the capacitance system.  Here a cell lives in ONE wave:
+//   * lane l owns the M CONSECUTIVE poses l*M+1 .. l*M+M (lane-major), so the chain neighbour
+//     of a slot is the previous slot of the same lane (a register); only slot 0 takes one DPP
+//     shift from the lane below.  Prefix sums are an in-lane serial pass + ONE wave scan,
+//     reductions are in-lane accumulation + ONE wave reduction.  No barrier anywhere.
+//   * the four waves of a workgroup (one per SIMD, up to 512 registers each) work on four
+//     DIFFERENT cells and fetch the next one from a global counter when done, so a CU always
+//     has four dog-legs in flight and nothing waits for the slowest wave of a cell.
+//   * the chain constants of the residual pass (5 measurement + 6 information values per edge)
+//     are staged ONCE per workgroup for the whole window of the launch and shared by every cell
+//     it solves (all cells of a launch use the same chain); M is odd so the stride-M ds_read_b64
+//     pattern is bank-conflict free.
+//   * trial poses / trial errors are not stored: a trial is one sweep that steps, evaluates and
+//     sums chi2 on the fly; an accepted trial is re-swept once to commit poses and errors.
+// Mathematics, dog-leg control flow and shortcuts are those of se2_cell.hpp.
+#pragma once
+#include "se2_cell.hpp"
+
+namespace ipc {
+
+template <int NL>
+struct WaveScratch {          // per wave, LDS
+    LoopConst lc[NL];
+    LoopState ls[2][NL];
+    double lvec[NL][2][3];
+    double red[32];
+    double gam[NL * 9];       // Gamma_l of the capacitance assembly
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// SPD solve A x = b by LDL^T (N = 3 or 6) on wave-uniform values; reciprocals by v_rcp_f64 + two
+// Newton steps.  Returns false when a pivot is not positive.
+template <int N>
+__device__ __forceinline__ bool ldl_solve(double (&A)[N][N], double (&b)[N])
+{
+    bool ok = true;
+    double inv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k] * A[k][k];
+        ok = ok && (d > 0);
+        double r = __builtin_amdgcn_rcp(d);
+        r = fma(fma(-d, r, 1.0), r, r);
+        r = fma(fma(-d, r, 1.0), r, r);
+        inv[j] = r;
+        A[j][j] = d;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k] * A[k][k];
+            A[i][j] = v * r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= A[i][k] * b[k];
+        b[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] *= inv[i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) v -= A[k][i] * b[k];
+        b[i] = v;
+    }
+    return ok;
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+// The per-slot loops are fully unrolled (the state lives in registers); without a fence the
+// scheduler interleaves all M slots and the temporaries of M slots are live at once (> 1000
+// VGPRs at M = 13).  One scheduling barrier per slot keeps the live set at state + one slot.
+#define IPC_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int M, int NL, bool STAGED>
+__device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
+                               WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res)
+{
+    constexpr int NS = NL * 3;
+    const int lane = threadIdx.x & 63;
+    const int j0 = lane * M + 1;                     // pose index of slot 0
+
+    // ---------------- loop constants -> LDS ----------------
+    if (lane < NL) {
+        const int l = lane, c = cand[l];
+        LoopConst& q = sh.lc[l];
+        q.f = P.cand_from[c] - lo_abs;
+        q.t = P.cand_to[c] - lo_abs;
+        q.lo = min(q.f, q.t);
+        q.hi = max(q.f, q.t);
+        q.sigma = q.t > q.f ? 1.0 : -1.0;
+        q.tzx = P.cand[(size_t)F_TZX * P.cstride + c];
+        q.tzy = P.cand[(size_t)F_TZY * P.cstride + c];
+        q.cz = P.cand[(size_t)F_CZ * P.cstride + c];
+        q.sz = P.cand[(size_t)F_SZ * P.cstride + c];
+        q.thz = P.cand[(size_t)F_THZ * P.cstride + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            q.om[k] = P.cand[(size_t)(F_OM + k) * P.cstride + c];
+            q.sg[k] = P.cand[(size_t)(F_SG + k) * P.cstride + c];
+        }
+    }
+
+    // ---------------- per-lane state ----------------
+    Pose2 X[M];
+    double ex[M], ey[M], eth[M];
+    double bx[M], by[M], bth[M];
+    double hx[M], hy[M], hth[M];
+    Pose2 gauge;
+    gauge.x = P.pose0[lo_abs];
+    gauge.y = P.pose0[(size_t)P.V + lo_abs];
+    gauge.th = P.pose0[(size_t)2 * P.V + lo_abs];
+    sincos_pi(gauge.th, gauge.s, gauge.c);
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        const int j = j0 + s;
+        const int ja = j <= L ? lo_abs + j : lo_abs;
+        X[s].x = P.pose0[ja];
+        X[s].y = P.pose0[(size_t)P.V + ja];
+        X[s].th = P.pose0[(size_t)2 * P.V + ja];
+        sincos_pi(X[s].th, X[s].s, X[s].c);
+        ex[s] = ey[s] = eth[s] = 0.0;
+        bx[s] = by[s] = bth[s] = 0.0;
+        hx[s] = hy[s] = hth[s] = 0.0;
+    }
+    wave_sync();                                     // sh.lc visible
+    int lf[NL], lt[NL], of[NL], sf[NL], ot[NL], st_[NL], llo[NL], lhi[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        lf[l] = __builtin_amdgcn_readfirstlane(sh.lc[l].f);
+        lt[l] = __builtin_amdgcn_readfirstlane(sh.lc[l].t);
+        llo[l] = min(lf[l], lt[l]); lhi[l] = max(lf[l], lt[l]);
+        of[l] = lf[l] > 0 ? (lf[l] - 1) / M : -1; sf[l] = lf[l] > 0 ? (lf[l] - 1) % M : -1;
+        ot[l] = lt[l] > 0 ? (lt[l] - 1) / M : -1; st_[l] = lt[l] > 0 ? (lt[l] - 1) % M : -1;
+    }
+    if (lane == 0) {                                 // gauge end points never change
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int bsel = 0; bsel < 2; ++bsel) {
+                double* pf = sh.ls[bsel][l].pf;
+                double* pt = sh.ls[bsel][l].pt;
+                if (lf[l] == 0) { pf[0] = gauge.x; pf[1] = gauge.y; pf[2] = gauge.th; pf[3] = gauge.c; pf[4] = gauge.s; }
+                if (lt[l] == 0) { pt[0] = gauge.x; pt[1] = gauge.y; pt[2] = gauge.th; pt[3] = gauge.c; pt[4] = gauge.s; }
+            }
+    }
+
+    // chain constants: local edge index of slot s is eloc + s (idle lanes are parked on edge 0;
+    // the partially filled lane reads up to M-1 records past the chain, which the window padding
+    // and the record-array padding cover)
+    // The constants are loop-invariant, so the compiler would hoist every load out of the dog-leg
+    // loop and pin 17 doubles per slot in registers; opaque() makes the index look modified, which
+    // keeps the loads where they are used.
+    int eloc = lane * M < L ? lane * M : 0;
+    auto opaque = [&]() { asm volatile("" : "+v"(eloc)); };
+    auto ldc = [&](int field, int s) -> double {
+        if (STAGED && field < (int)F_SG) return cst[field * wstride + (lo_abs - wlo + eloc) + s];
+        return P.chain[(size_t)field * P.estride + (lo_abs + eloc) + s];
+    };
+    auto ldsym = [&](int field0, int s) -> Sym3 {
+        Sym3 m;
+        m.a00 = ldc(field0 + 0, s); m.a01 = ldc(field0 + 1, s); m.a02 = ldc(field0 + 2, s);
+        m.a11 = ldc(field0 + 3, s); m.a12 = ldc(field0 + 4, s); m.a22 = ldc(field0 + 5, s);
+        return m;
+    };
+    // pose j-1 of slot 0: slot M-1 of the lane below (lane 0: the gauge)
+    auto prev0 = [&](const Pose2& last) -> Pose2 {
+        Pose2 p;
+        p.x = lane_prev(last.x, gauge.x); p.y = lane_prev(last.y, gauge.y); p.th = lane_prev(last.th, gauge.th);
+        p.c = lane_prev(last.c, gauge.c); p.s = lane_prev(last.s, gauge.s);
+        return p;
+    };
+
+    auto loop_eval = [&](int l, int bsel) -> double {
+        const LoopConst& q = sh.lc[l];
+        LoopState& st = sh.ls[bsel][l];
+        Pose2 a{st.pf[0], st.pf[1], st.pf[2], st.pf[3], st.pf[4]};
+        Pose2 b{st.pt[0], st.pt[1], st.pt[2], st.pt[3], st.pt[4]};
+        double e0, e1, e2;
+        se2_error(a, b, q.tzx, q.tzy, q.cz, q.sz, q.thz, e0, e1, e2);
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        double q0, q1, q2;
+        om.mul(e0, e1, e2, q0, q1, q2);
+        const double chi = e0 * q0 + e1 * q1 + e2 * q2;
+        st.e[0] = e0; st.e[1] = e1; st.e[2] = e2;
+        st.chi = chi;
+        return chi;
+    };
+    int cur = 0;
+    auto loop_force = [&](int l) {
+        const LoopConst& q = sh.lc[l];
+        LoopState& st = sh.ls[cur][l];
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        double q0, q1, q2;
+        om.mul(st.e[0], st.e[1], st.e[2], q0, q1, q2);
+        const double cP = st.pf[3] * q.cz - st.pf[4] * q.sz, sP = st.pf[4] * q.cz + st.pf[3] * q.sz;
+        st.g[0] = cP * q0 - sP * q1; st.g[1] = sP * q0 + cP * q1; st.g[2] = q2;
+    };
+    auto loop_quad = [&](int l) -> double {
+        const LoopConst& q = sh.lc[l];
+        const LoopState& st = sh.ls[cur][l];
+        Pose2 a{st.pf[0], st.pf[1], st.pf[2], st.pf[3], st.pf[4]};
+        Pose2 b{st.pt[0], st.pt[1], st.pt[2], st.pt[3], st.pt[4]};
+        double wx, wy, wth;
+        se2_apply_J(a, b, q.cz, q.sz, sh.lvec[l][0][0], sh.lvec[l][0][1], sh.lvec[l][0][2], sh.lvec[l][1][0],
+                    sh.lvec[l][1][1], sh.lvec[l][1][2], wx, wy, wth);
+        Sym3 om{q.om[0], q.om[1], q.om[2], q.om[3], q.om[4], q.om[5]};
+        return om.quad(wx, wy, wth);
+    };
+
+    // One sweep over the chain.
+    //   MODE 0: errors of the committed poses X            -> e, chi2, loop state buffer `bsel`
+    //   MODE 1: trial poses X (+) (p b + q h), not stored  -> chi2, loop state buffer `bsel`, changed
+    //   MODE 2: commit X <- X (+) (p b + q h)              -> X, e
+    // big (wave-uniform): some angle moves by >= 2^-6 rad (full sincos instead of the small
+    // rotation).  A run-time flag on purpose: as two instantiations under one branch, the compiler
+    // hoists the common half of every slot above the branch and keeps it alive.
+    bool sweepChanged = false;
+    // Identical sub-expressions recur in every phase (P_j, kappa_j, dt_j, range masks ...); the
+    // compiler would keep them alive per slot from one phase to the next.  Laundering the state
+    // at the phase boundaries (no instructions) makes it recompute them instead.
+    auto launder = [&]() {
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            asm volatile("" : "+v"(X[s].x), "+v"(X[s].y), "+v"(X[s].c), "+v"(X[s].s));
+            asm volatile("" : "+v"(ex[s]), "+v"(ey[s]), "+v"(eth[s]));
+        }
+    };
+    auto sweep = [&](auto mode_c, bool big, double p, double q, int bsel) -> double {
+        constexpr int MODE = decltype(mode_c)::value;
+        opaque();
+        launder();
+        // the commit sweep repeats the trial sweep's arithmetic; hide the coefficients so the
+        // compiler cannot keep the trial's poses and errors alive to reuse them
+        asm volatile("" : "+v"(p), "+v"(q));
+        auto stepped = [&](int s) -> Pose2 {
+            Pose2 Y;
+            Y.x = X[s].x + fma(p, bx[s], q * hx[s]);
+            Y.y = X[s].y + fma(p, by[s], q * hy[s]);
+            Y.th = wrap_pi(X[s].th + fma(p, bth[s], q * hth[s]));
+            if (big) sincos_pi(Y.th, Y.s, Y.c);
+            else rotate_small(X[s].c, X[s].s, Y.th - X[s].th, Y.c, Y.s);
+            return Y;
+        };
+        const Pose2 last = MODE == 0 ? X[M - 1] : stepped(M - 1);
+        Pose2 prev = prev0(last);
+        double part = 0.0;
+        bool changed = false;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            const Pose2 Y = MODE == 0 ? X[s] : (s == M - 1 ? last : stepped(s));
+            const bool v = j0 + s <= L;
+            if (MODE == 1) changed |= v && ((Y.x != X[s].x) || (Y.y != X[s].y) || (Y.th != X[s].th));
+            double e0, e1, e2;
+            se2_error(prev, Y, ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+            if (MODE != 2) {
+                const double c2 = ldsym(F_OM, s).quad(e0, e1, e2);
+                part += v ? c2 : 0.0;
+            }
+            if (MODE != 1) { ex[s] = v ? e0 : 0.0; ey[s] = v ? e1 : 0.0; eth[s] = v ? e2 : 0.0; }
+            if (MODE != 2) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    if (sf[l] == s && lane == of[l]) {
+                        double* w = sh.ls[bsel][l].pf;
+                        w[0] = Y.x; w[1] = Y.y; w[2] = Y.th; w[3] = Y.c; w[4] = Y.s;
+                    }
+                    if (st_[l] == s && lane == ot[l]) {
+                        double* w = sh.ls[bsel][l].pt;
+                        w[0] = Y.x; w[1] = Y.y; w[2] = Y.th; w[3] = Y.c; w[4] = Y.s;
+                    }
+                }
+            }
+            if (MODE == 2) X[s] = Y;
+            prev = Y;
+            IPC_SLOT_FENCE();
+        }
+        if (MODE == 2) return 0.0;
+        wave_sync();
+        if (lane < NL) part += loop_eval(lane, bsel);
+        if (MODE == 1) sweepChanged = __ballot(changed) != 0ull;
+        return wave_sum(part);
+    };
+
+    // ---------------- initial errors (consensus_utils.cpp:11) ----------------
+    int evals = 1;
+    double currentChi = sweep(IntC<0>{}, false, 0.0, 0.0, cur);
+
+    // ---------------- dog-leg (g2o OptimizationAlgorithmDogleg::solve) ----------------
+    double delta = 1e4;
+    const int maxTrials = 100;
+    int it_done = 0, tries_total = 0, flags = 0;
+
+    for (int it = 0; it < iterations; ++it) {
+        // ---- phase A: forces g, hand-back m -> b ----
+        opaque();
+        launder();
+        if (lane < NL) loop_force(lane);
+        wave_sync();
+        const Pose2 a0 = prev0(X[M - 1]);
+        auto force = [&](int s, const Pose2& a, double& gx, double& gy, double& gth, double& mx, double& my,
+                         double& mth) {
+            const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+            const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
+            double qx, qy, qth;
+            ldsym(F_OM, s).mul(ex[s], ey[s], eth[s], qx, qy, qth);      // e is zero on idle slots
+            gx = cP * qx - sP * qy;
+            gy = sP * qx + cP * qy;
+            gth = qth;
+            const double dx = X[s].x - a.x, dy = X[s].y - a.y;
+            mx = gx; my = gy;
+            mth = gth + (-dy * gx + dx * gy);
+        };
+        double bbp = 0.0;
+        {
+            double g0x, g0y, g0th, m0x, m0y, m0th;
+            force(0, a0, g0x, g0y, g0th, m0x, m0y, m0th);
+            double nx = lane_next(m0x, 0.0), ny = lane_next(m0y, 0.0), nth = lane_next(m0th, 0.0);
+#pragma unroll
+            for (int s = M - 1; s >= 0; --s) {
+                double gx, gy, gth, mx, my, mth;
+                if (s == 0) { gx = g0x; gy = g0y; gth = g0th; mx = m0x; my = m0y; mth = m0th; }
+                else force(s, X[s - 1], gx, gy, gth, mx, my, mth);
+                const bool v = j0 + s <= L;
+                double tx = nx - gx, ty = ny - gy, tth = nth - gth;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const LoopState& st = sh.ls[cur][l];
+                    if (st_[l] == s && lane == ot[l]) { tx -= st.g[0]; ty -= st.g[1]; tth -= st.g[2]; }
+                    if (sf[l] == s && lane == of[l]) {
+                        const double dx = st.pt[0] - st.pf[0], dy = st.pt[1] - st.pf[1];
+                        tx += st.g[0]; ty += st.g[1];
+                        tth += st.g[2] + (-dy * st.g[0] + dx * st.g[1]);
+                    }
+                }
+                bx[s] = v ? tx : 0.0; by[s] = v ? ty : 0.0; bth[s] = v ? tth : 0.0;
+                bbp += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
+                nx = mx; ny = my; nth = mth;
+                IPC_SLOT_FENCE();
+            }
+        }
+        // ---- phase B: b^T b, b^T H b, capacitance partials, solve ----
+        double bb, bHb, alpha, hsdNorm;
+        double nu[NL][3];
+        opaque();
+        launder();
+        {
+            // b at the loop end points (the gauge end point carries zero)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                if (lane == 0) {
+                    if (lf[l] == 0) { sh.lvec[l][0][0] = 0.0; sh.lvec[l][0][1] = 0.0; sh.lvec[l][0][2] = 0.0; }
+                    if (lt[l] == 0) { sh.lvec[l][1][0] = 0.0; sh.lvec[l][1][1] = 0.0; sh.lvec[l][1][2] = 0.0; }
+                }
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    if (sf[l] == s && lane == of[l]) { sh.lvec[l][0][0] = bx[s]; sh.lvec[l][0][1] = by[s]; sh.lvec[l][0][2] = bth[s]; }
+                    if (st_[l] == s && lane == ot[l]) { sh.lvec[l][1][0] = bx[s]; sh.lvec[l][1][1] = by[s]; sh.lvec[l][1][2] = bth[s]; }
+                }
+            }
+            // group 1: b^T b, b^T H b, W_1 (3), M_11 (6); group 2: W_2 (3), M_22 (6), M_12 (6)
+            double v1[16], v2[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { v1[k] = 0.0; v2[k] = 0.0; }
+            v1[0] = bbp;
+            double qbx = lane_prev(bx[M - 1], 0.0), qby = lane_prev(by[M - 1], 0.0), qbth = lane_prev(bth[M - 1], 0.0);
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const Pose2& a = s == 0 ? a0 : X[s - 1];
+                const bool v = j0 + s <= L;
+                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                double wx, wy, wth;
+                se2_apply_J(a, X[s], cz, sz, qbx, qby, qbth, bx[s], by[s], bth[s], wx, wy, wth);
+                const double hq = ldsym(F_OM, s).quad(wx, wy, wth);
+                v1[1] += v ? hq : 0.0;
+                const Sym3 sg = ldsym(F_SG, s);
+                const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
+                const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;
+                const double cc = c * c, ss = sn * sn, cs = c * sn;
+                const double C00 = cc * sg.a00 - 2 * cs * sg.a01 + ss * sg.a11;
+                const double C01 = cs * (sg.a00 - sg.a11) + (cc - ss) * sg.a01;
+                const double C11 = ss * sg.a00 + 2 * cs * sg.a01 + cc * sg.a11;
+                const double c0 = c * sg.a02 - sn * sg.a12, c1 = sn * sg.a02 + c * sg.a12;
+                const double sth = sg.a22;
+                double psi[6];
+                psi[2] = c0 - sth * kx;
+                psi[4] = c1 - sth * ky;
+                psi[0] = C00 - kx * c0 - kx * psi[2];
+                psi[1] = C01 - kx * c1 - ky * psi[2];
+                psi[3] = C11 - ky * c1 - ky * psi[4];
+                psi[5] = sth;
+                const double w0 = c * ex[s] - sn * ey[s] - kx * eth[s];
+                const double w1 = sn * ex[s] + c * ey[s] - ky * eth[s];
+                const double w2 = eth[s];
+                const int j = j0 + s;
+                const double m1 = (v && j > llo[0] && j <= lhi[0]) ? 1.0 : 0.0;
+                v1[2] += m1 * w0; v1[3] += m1 * w1; v1[4] += m1 * w2;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v1[5 + k] += m1 * psi[k];
+                if constexpr (NL == 2) {
+                    const double m2 = (v && j > llo[1] && j <= lhi[1]) ? 1.0 : 0.0;
+                    const double m12 = m1 * m2;
+                    v2[0] += m2 * w0; v2[1] += m2 * w1; v2[2] += m2 * w2;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { v2[3 + k] += m2 * psi[k]; v2[9 + k] += m12 * psi[k]; }
+                }
+                qbx = bx[s]; qby = by[s]; qbth = bth[s];
+                IPC_SLOT_FENCE();
+            }
+            wave_sum16_store(v1, &sh.red[0]);
+            if constexpr (NL == 2) wave_sum16_store(v2, &sh.red[16]);
+            wave_sync();
+            // ---- capacitance solve, lane-parallel (a uniform 6x6 solve in registers would pin ~150
+            // VGPRs while the whole chain state is live):
+            //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> gam[.]
+            //   lane r*(NS+1)+c  : S[r][c] (c < NS) / rhs d[r] (c == NS), then Gauss-Jordan in place
+            const double* wt = sh.red;
+            if (lane < NL * 9) {
+                const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
+                const LoopConst& q = sh.lc[l];
+                const LoopState& st = sh.ls[cur][l];
+                const double Aq = st.pf[3] * q.cz - st.pf[4] * q.sz, Bq = st.pf[4] * q.cz + st.pf[3] * q.sz;
+                const double Kx = -(st.pt[1] - gauge.y), Ky = st.pt[0] - gauge.x;
+                double g;
+                if (i == 0) g = a == 0 ? Aq : (a == 1 ? Bq : Aq * Kx + Bq * Ky);
+                else if (i == 1) g = a == 0 ? -Bq : (a == 1 ? Aq : -Bq * Kx + Aq * Ky);
+                else g = a == 2 ? 1.0 : 0.0;
+                sh.gam[lane] = q.sigma * g;
+            }
+            wave_sync();
+            constexpr int RS = NS + 1;                    // row stride of the augmented system
+            double val = 0.0;
+            const int r = lane / RS, c = lane % RS;
+            if (lane < NS * RS) {
+                const int l1 = r / 3, i = r % 3;
+                const double g10 = sh.gam[l1 * 9 + i * 3], g11 = sh.gam[l1 * 9 + i * 3 + 1], g12 = sh.gam[l1 * 9 + i * 3 + 2];
+                if (c < NS) {
+                    const int l2 = c / 3, k = c % 3;
+                    const int mb = l1 == l2 ? (l1 == 0 ? 5 : 19) : 25;
+                    const double m00 = wt[mb], m01 = wt[mb + 1], m02 = wt[mb + 2], m11 = wt[mb + 3], m12 = wt[mb + 4], m22 = wt[mb + 5];
+                    const double t0 = g10 * m00 + g11 * m01 + g12 * m02;
+                    const double t1 = g10 * m01 + g11 * m11 + g12 * m12;
+                    const double t2 = g10 * m02 + g11 * m12 + g12 * m22;
+                    val = t0 * sh.gam[l2 * 9 + k * 3] + t1 * sh.gam[l2 * 9 + k * 3 + 1] + t2 * sh.gam[l2 * 9 + k * 3 + 2];
+                    if (l1 == l2) {
+                        const int lo_ = i < k ? i : k, hi_ = i < k ? k : i;
+                        val += sh.lc[l1].sg[lo_ * 3 - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)];
+                    }
+                } else {
+                    const int wb = l1 == 0 ? 2 : 16;
+                    val = sh.ls[cur][l1].e[i] - (g10 * wt[wb] + g11 * wt[wb + 1] + g12 * wt[wb + 2]);
+                }
+            }
+            bool okS = true;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const double piv = read_lane(val, k * RS + k);
+                okS = okS && (piv > 0);
+                double inv = __builtin_amdgcn_rcp(piv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                const double rowk = __shfl(val, k * RS + c, 64);
+                const double colk = __shfl(val, r * RS + k, 64);
+                val = (r == k) ? rowk * inv : fma(-(colk * rowk), inv, val);
+            }
+            {   // nu_l[cc] = sum_rr Gamma_l[rr][cc] mu_{3l+rr}; mu_r sits in lane r*RS + NS
+                const int l = (lane < NS) ? lane / 3 : 0, cc = lane % 3;
+                double nv = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const double mu_r = __shfl(val, (3 * l + rr) * RS + NS, 64);
+                    nv += sh.gam[l * 9 + rr * 3 + cc] * mu_r;
+                }
+#pragma unroll
+                for (int l2 = 0; l2 < NL; ++l2)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nu[l2][k] = read_lane(nv, 3 * l2 + k);
+            }
+            bb = wt[0];
+            bHb = wt[1];
+            {
+                const double lq = lane < NL ? loop_quad(lane) : 0.0;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) bHb += read_lane(lq, l);
+            }
+            if (!okS) { flags |= 2; break; }
+            alpha = bb / bHb;
+            hsdNorm = sqrt(alpha * alpha * bb);
+        }
+        // ---- phase C: u, rho, prefix sums -> h_gn; |h|^2, b.h (h^T H h = b.h) ----
+        double hgnNorm, bh, hHh;
+        opaque();
+        launder();
+        {
+            // rho into (hx, hy, hth); theta prefix in-lane
+            double run = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const Pose2& a = s == 0 ? a0 : X[s - 1];
+                const int j = j0 + s;
+                const bool v = j <= L;
+                const double m1 = (v && j > llo[0] && j <= lhi[0]) ? 1.0 : 0.0;
+                double n0 = m1 * nu[0][0], n1 = m1 * nu[0][1], n2 = m1 * nu[0][2];
+                if constexpr (NL == 2) {
+                    const double m2 = (v && j > llo[1] && j <= lhi[1]) ? 1.0 : 0.0;
+                    n0 += m2 * nu[1][0]; n1 += m2 * nu[1][1]; n2 += m2 * nu[1][2];
+                }
+                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
+                const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;
+                const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
+                double vx, vy, vth;
+                ldsym(F_SG, s).mul(wx, wy, wth, vx, vy, vth);
+                const double ux = -vx - ex[s], uy = -vy - ey[s], uth = -vth - eth[s];
+                hx[s] = v ? c * ux - sn * uy : 0.0;
+                hy[s] = v ? sn * ux + c * uy : 0.0;
+                run += v ? uth : 0.0;
+                hth[s] = run;                        // in-lane inclusive prefix of rho_theta
+                IPC_SLOT_FENCE();
+            }
+            const double offT = wave_inclusive_scan(run) - run;        // h_theta of the lane's predecessor pose
+            double rx = 0.0, ry = 0.0, thPrev = offT;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const Pose2& a = s == 0 ? a0 : X[s - 1];
+                const bool v = j0 + s <= L;
+                hth[s] += offT;
+                const double dx = X[s].x - a.x, dy = X[s].y - a.y;
+                rx += v ? hx[s] - dy * thPrev : 0.0;
+                ry += v ? hy[s] + dx * thPrev : 0.0;
+                hx[s] = rx; hy[s] = ry;
+                thPrev = hth[s];
+                IPC_SLOT_FENCE();
+            }
+            const double offX = wave_inclusive_scan(rx) - rx, offY = wave_inclusive_scan(ry) - ry;
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const bool v = j0 + s <= L;
+                hx[s] = v ? hx[s] + offX : 0.0;
+                hy[s] = v ? hy[s] + offY : 0.0;
+                hth[s] = v ? hth[s] : 0.0;
+                p0 += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
+                p1 += bx[s] * hx[s] + by[s] * hy[s] + bth[s] * hth[s];
+            }
+            hgnNorm = sqrt(wave_sum(p0));
+            bh = wave_sum(p1);
+            hHh = bh;
+        }
+        // ---- trial loop ----
+        bool goodStep = false;
+        int numTries = 0;
+        do {
+            ++numTries;
+            int stepType;                             // 0 GN, 1 SD, 2 DL
+            double beta = 0.0, sdScale = 0.0;
+            if (hgnNorm < delta) stepType = 0;
+            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
+            else {
+                stepType = 2;
+                double p0 = 0.0, p1 = 0.0;            // c = hsd.(hgn-hsd), |hgn-hsd|^2
+#pragma unroll
+                for (int s = 0; s < M; ++s) {
+                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
+                    const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
+                    p0 += sx * ax + sy * ay + sth * ath;
+                    p1 += ax * ax + ay * ay + ath * ath;
+                }
+                const double c = wave_sum(p0), bma = wave_sum(p1), hsdSq = alpha * alpha * bb;
+                if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
+                else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
+            }
+            double pcoef, qcoef, hdlNorm;
+            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
+            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
+            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double bhdl = pcoef * bb + qcoef * bh;
+            double linearGain = -1 * hdlHhdl + 2 * bhdl;
+            bool big = false;
+            double pc2 = pcoef, qc2 = qcoef;
+            asm volatile("" : "+v"(pc2), "+v"(qc2));
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const double thn = wrap_pi(X[s].th + fma(pc2, bth[s], qc2 * hth[s]));
+                big |= fabs(thn - X[s].th) >= 0.015625;
+            }
+            const bool anyBig = __ballot(big) != 0ull;
+            const int trial = cur ^ 1;
+            const double newChi = sweep(IntC<1>{}, anyBig, pcoef, qcoef, trial);
+            const bool anyChanged = stepType == 1 ? sweepChanged : true;
+            ++evals;
+            const double nonLinearGain = currentChi - newChi;
+            if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
+            const bool linPos = linearGain > 0;
+            auto rho_gt = [&](double t) { return linPos ? nonLinearGain > t * linearGain : nonLinearGain < t * linearGain; };
+            auto rho_lt = [&](double t) { return linPos ? nonLinearGain < t * linearGain : nonLinearGain > t * linearGain; };
+            if (rho_gt(0.0)) {                        // rho > 0, discardTop: commit the trial
+                goodStep = true;
+                currentChi = newChi;
+                cur = trial;
+                sweep(IntC<2>{}, anyBig, pcoef, qcoef, trial);
+            }
+            if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
+            else if (rho_lt(0.25)) delta *= 0.5;
+            if (!goodStep) {
+                if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                } else if (stepType == 1 && !anyChanged) {
+                    numTries = maxTrials;
+                }
+            }
+        } while (!goodStep && numTries < maxTrials);
+        it_done = it + 1;
+        tries_total += numTries;
+        if (numTries == maxTrials || !goodStep) { flags |= 1; break; }
+    }
+
+    // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
+    double mx = 0.0;
+    bool nan = false;
+    opaque();
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        if (j0 + s > L) continue;
+        const double c = ldsym(F_OM, s).quad(ex[s], ey[s], eth[s]);
+        if (c != c) nan = true;
+        else mx = fmax(mx, c);
+    }
+    mx = wave_max(mx);
+    nan = __ballot(nan) != 0ull;
+    wave_sync();
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const double c = sh.ls[cur][l].chi;
+        if (c != c) nan = true;
+        else mx = fmax(mx, c);
+    }
+    if (nan) mx = __longlong_as_double(0x7ff8000000000000ll);
+    res.max_chi2 = mx;
+    res.chi2_total = currentChi;
+    res.iterations = it_done;
+    res.tries = tries_total;
+    res.flags = flags;
+    res.evals = evals;
+}
+
+}  // namespace ipc
