@@ -70,6 +70,10 @@ def build_workload(name):
         g = g2
         cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=60)
         desc = "small sphere SE3 synthetic (V=500, 60 true loops) + 60 injected outliers"
+    elif name == "T700":      # every chain <= 699 poses: one kernel variant can take all cells (variant A/B timing)
+        g = synth.inject_outliers(synth._se2_graph(700, 60, seed=7, laps=4.0), 300, seed=70)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=60)
+        desc = "SE2 synthetic (V=700, 60 true loops) + 300 injected outliers"
     elif name == "tiny":
         g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)

@@ -940,6 +940,28 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         // ---- trial loop ----
         bool goodStep = false;
         int numTries = 0;
+        bool haveBlend = false;
+        double blendC = 0.0, blendBma = 0.0;          // hsd.(hgn-hsd), |hgn-hsd|^2: independent of delta
+        auto blend_sums = [&]() {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                if (!valid[s]) continue;
+                const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
+                const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
+                p0 += sx * ax + sy * ay + sth * ath;
+                p1 += ax * ax + ay * ay + ath * ath;
+            }
+            p0 = wave_sum(p0); p1 = wave_sum(p1);
+            Se2Scratch<W, NL>& S = sh.scr[phase & 1];
+            if (lane == 0) { S.red[wave] = p0; S.red[16 + wave] = p1; }
+            __syncthreads();
+            double tot[2];
+            gather_totals<2>(S.red, W, tot);
+            ++phase;
+            blendC = tot[0]; blendBma = tot[1];
+            haveBlend = true;
+        };
         do {
             ++numTries;
             int stepType;                             // 0 GN, 1 SD, 2 DL
@@ -948,23 +970,8 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
             else {
                 stepType = 2;
-                double p0 = 0.0, p1 = 0.0;            // c = hsd.(hgn-hsd), |hgn-hsd|^2
-#pragma unroll
-                for (int s = 0; s < M; ++s) {
-                    if (!valid[s]) continue;
-                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
-                    const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
-                    p0 += sx * ax + sy * ay + sth * ath;
-                    p1 += ax * ax + ay * ay + ath * ath;
-                }
-                p0 = wave_sum(p0); p1 = wave_sum(p1);
-                Se2Scratch<W, NL>& S = sh.scr[phase & 1];
-                if (lane == 0) { S.red[wave] = p0; S.red[16 + wave] = p1; }
-                __syncthreads();
-                double tot[2];
-                gather_totals<2>(S.red, W, tot);
-                ++phase;
-                const double c = tot[0], bma = tot[1], hsdSq = alpha * alpha * bb;
+                if (!haveBlend) blend_sums();         // c = hsd.(hgn-hsd), |hgn-hsd|^2, once per iteration
+                const double c = blendC, bma = blendBma, hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
                 else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
             }
