@@ -188,7 +188,7 @@ def main():
         import csv
         f = w = 0.0
         for r in csv.DictReader(open(pmc_csv)):
-            if "_cells_kernel" in r["kernel"]:
+            if "_cells_kernel" in r["kernel"] or "_wave_kernel" in r["kernel"]:
                 if r["counter"] == "FETCH_SIZE":
                     f += float(r["sum_value"])
                 elif r["counter"] == "WRITE_SIZE":
@@ -200,7 +200,8 @@ def main():
                 "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
                                 "L2-resident" % args.workload,
-                "kernel": "se%d_cells_kernel<W,M,NL> (%d launches per step, one per chain-length bin)" % (g.dim, launches),
+                "kernel": "se%d_cells_kernel<W,M,NL>%s (%d launches per step, one per chain-length bin and loop count)" % (
+                    g.dim, " + se2_wave_kernel<M,NL,STAGED>" if g.dim == 2 else "", launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
