@@ -140,6 +140,34 @@ def test_full_size_c1_properties_and_sampled_parity(oracle):
     assert worst <= 1e-5
 
 
+def test_long_chain_exercises_unstaged_constant_paths(oracle):
+    """V = 2400: the whole-chain window no longer fits the LDS, so the wave kernels read their
+    constants from L2, and chains beyond 1536 poses run the block kernel without staging."""
+    from ipc_amd import synth
+    O = oracle
+    g = synth._se2_graph(2400, 40, seed=9, laps=14.0, name="long")
+    g = synth.inject_outliers(g, 30, seed=2, local=True)        # spans 2..20 -> w1 cells
+    g = synth.inject_outliers(g, 8, seed=3)
+    eng, cfg = _engine(g)
+    bits, acc = eng.run()
+    cells = eng.cell_info()
+    L = cells["hi"] - cells["lo"]
+    assert L.min() <= 20 and L.max() > 1536
+    order = np.argsort(L)
+    short = order[L[order] <= 320]
+    mid = order[(L[order] > 320) & (L[order] <= 1536)]
+    long_ = order[L[order] > 1536]
+    rng = np.random.default_rng(1)
+    pick = np.concatenate([rng.choice(short, 25, replace=False), rng.choice(mid, 6, replace=False),
+                           long_[:2], long_[-1:]])
+    worst = _compare_cells(O, g, cfg, eng, cells[pick])
+    assert worst <= 1e-5
+    from ipc_amd.consensus import unpack_bits
+    C = unpack_bits(bits, eng.N)
+    assert np.array_equal(C, C.T)
+    assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
+
+
 def test_edge_cases_reversed_duplicate_and_full_span(oracle):
     """Loop edges written high->low (the reference's graph_fixer exists because datasets contain
     them), duplicated candidates, touching intervals, and a candidate spanning the whole chain."""
