@@ -62,6 +62,47 @@ def test_usage_and_loud_errors(built, tmp_path):
     assert r.returncode == 1 and "not a 2D graph" in r.stderr
 
 
+GEN_CASES = [
+    ("small_se2_clean.g2o", "small_se2_spoiled_n6_seed3.g2o", ["-n", "6", "--seed", "3"]),
+    ("small_se2_clean.g2o", "small_se2_local_spoiled_n5_seed9.g2o", ["-n", "5", "--seed", "9", "--local"]),
+    ("small_se2_clean.g2o", "small_se2_group_spoiled_n3_seed5.g2o", ["-n", "3", "--seed", "5", "-g", "2"]),
+    ("small_se3_clean.g2o", "small_se3_spoiled_n5_seed4.g2o", ["-n", "5", "--seed", "4"]),
+]
+
+
+@pytest.mark.parametrize("clean,spoiled,flags", GEN_CASES)
+def test_generate_dataset_reproduces_the_reference_script_byte_for_byte(built, tmp_path, clean, spoiled, flags):
+    """The golden *_spoiled_* files are outputs of the reference's scripts/generateDataset.py
+    (tests/golden/make_golden.py); the C++ generator must write the same bytes."""
+    out = str(tmp_path / "out.g2o")
+    r = subprocess.run([os.path.join(HOST, "generateDataset"), "-i", os.path.join(GOLD, clean), "-o", out] + flags,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(os.path.join(GOLD, spoiled), "rb").read()
+
+
+@pytest.mark.parametrize("dim,n,seed,extra", [(2, 1000, 1000, []), (3, 300, 77, []), (2, 50, 5, ["-p"]),
+                                               (2, 40, 6, ["--information=42"])])
+def test_generate_dataset_matches_python_generator(built, tmp_path, dim, n, seed, extra):
+    """Same draws as ipc_amd.synth.sample_outliers (which wraps CPython's own random module)."""
+    from ipc_amd import graphio, synth
+    g = synth.small_se2() if dim == 2 else synth.small_se3()
+    clean, out = str(tmp_path / "clean.g2o"), str(tmp_path / "out.g2o")
+    graphio.write_g2o(clean, g)
+    r = subprocess.run([os.path.join(HOST, "generateDataset"), "-i", clean, "-o", out, "-n", str(n), "--seed",
+                        str(seed)] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = graphio.read_g2o(out)
+    ids, meas = synth.sample_outliers(dim, g.V, n, seed, perfect="-p" in extra)
+    assert got.N == g.N + n
+    assert np.array_equal(got.loop_ids[g.N:], ids)
+    assert np.array_equal(got.loop_meas[g.N:], meas)
+    if "--information=42" in extra:
+        assert np.array_equal(got.loop_info[g.N:], np.tile([42.0, 0, 0, 42.0, 0, 42.0], (n, 1)))
+    else:
+        assert np.array_equal(got.loop_info[g.N:], np.tile(g.loop_info[0], (n, 1)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim", [2, 3])
 def test_tester_outputs_match_python_path(built, tmp_path, dim):
