@@ -129,8 +129,8 @@ int ipc_synchronize(ipc_engine_t* h);
 
 /* ---- faithful incremental mode and final map -------------------
  * The reference's own sequential algorithm on the GPU: state = current pose estimates + the
- * consensus set, one cluster solve per candidate.  SE2 engines only for now (SE3 returns
- * IPC_ERR_LIMIT). */
+ * consensus set, one cluster solve per candidate.  Poses are SE2 [V][3] (x y theta) or SE3
+ * [V][12] (R row-major, t), as in ipc_initial_poses(). */
 
 /* Outcome of one cluster solve. */
 typedef struct {
@@ -165,12 +165,12 @@ int ipc_remove_from_consensus(ipc_engine_t* h, int k, int* removed);
  * pair, then re-sorts the set by cmpEdgesTime (stable). */
 int ipc_add_to_consensus(ipc_engine_t* h, int k);
 
-/* Current pose estimates (the g2o vertex estimates the reference mutates), SE2 [V][3]. */
+/* Current pose estimates (the g2o vertex estimates the reference mutates). */
 int ipc_current_poses(ipc_engine_t* h, double* poses_out);
 
 /* Final map (src/simulation.cpp:50-65): open-loop guess, odometry information back to
  * (info * s) / s, every candidate with accepted[k] != 0, optimize(iterations) with vertex 0
- * fixed (the harness uses 1000).  poses_out [V][3] and info may be NULL. */
+ * fixed (the harness uses 1000).  poses_out and info may be NULL. */
 int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int iterations, double* poses_out,
                        ipc_check_info_t* info);
 

@@ -127,15 +127,15 @@ class IPC:
         self._max_consensus_set = self._consensus()
 
     def current_poses(self):
-        out = np.zeros((self.graph.V, 3))
+        out = np.zeros((self.graph.V, 3 if self.dim == 2 else 12))
         capi.check(self.lib.ipc_current_poses(self.h, _p(out)))
         return out
 
     def final_optimize(self, accepted, iterations=1000):
-        """The harness's final map (reference src/simulation.cpp:50-65): returns (poses [V,3],
-        CheckInfo with chi2_total)."""
+        """The harness's final map (reference src/simulation.cpp:50-65): returns (poses [V,3] or
+        [V,12] (R row-major, t), CheckInfo with chi2_total)."""
         acc = np.ascontiguousarray(accepted, dtype=np.uint8)
-        out = np.zeros((self.graph.V, 3))
+        out = np.zeros((self.graph.V, 3 if self.dim == 2 else 12))
         info = capi.CheckInfo()
         capi.check(self.lib.ipc_final_optimize(self.h, _p(acc), int(iterations), _p(out), C.byref(info)))
         return out, info

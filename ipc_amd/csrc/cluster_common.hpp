@@ -1,0 +1,206 @@
+// Shared pieces of the cluster solvers (cluster_se2.hpp, cluster_se3.hpp): grid-kernel reduction
+// helpers, the one-workgroup prefix sum, the loop tables and the host-side dog-leg control flow
+// (g2o OptimizationAlgorithmDogleg::solve with the analytic gains and exact shortcuts of the cell
+// kernels).  The pose-type specific work hides behind an `Ops` object.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "block_prims.hpp"
+#include "dense_chol.hpp"
+
+namespace ipc {
+
+#define IPC_CL_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+constexpr int kGB = 256;                     // threads per block of the grid kernels
+
+template <int K>
+__device__ __forceinline__ void gk_block_reduce_store(double (&v)[K], double* partial_row)
+{
+    __shared__ double shm[K][kGB];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) shm[k][t] = v[k];
+    __syncthreads();
+    for (int s = kGB / 2; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) shm[k][t] += shm[k][t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) partial_row[k] = shm[k][0];
+    }
+}
+
+// sum of the per-block partials in block order (deterministic) -> scal[off + k]
+__global__ void gk_sum(const double* partial, int nblocks, int K, double* scal, int off)
+{
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double acc = 0.0;
+    for (int bq = 0; bq < nblocks; ++bq) acc += partial[bq * 4 + k];
+    scal[off + k] = acc;
+}
+
+// in-place inclusive prefix sums over indices 1..L of K arrays (row length ld), one workgroup
+__global__ __launch_bounds__(1024) void gk_scan(double* arr, int K, int L, int ld)
+{
+    __shared__ double wsum[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int k = 0; k < K; ++k) {
+        double* a = arr + (size_t)k * ld;
+        double carry = 0.0;
+        for (int base = 1; base <= L; base += 1024) {
+            const int i = base + tid;
+            double v = i <= L ? a[i] : 0.0;
+            v = wave_inclusive_scan(v);
+            if (lane == 63) wsum[wave] = v;
+            __syncthreads();
+            double off = carry;
+            for (int w = 0; w < wave; ++w) off += wsum[w];
+            double tot = carry;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            if (i <= L) a[i] = v + off;
+            carry = tot;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct ClusterOut {
+    double max_chi2 = 0.0, chi2_total = 0.0, chi2_initial = 0.0;
+    int iterations = 0, tries = 0, flags = 0, evals = 0;    // flags: 1 terminated, 2 solve failed
+};
+
+
+// Loop tables of a cluster in one int array (host layout == device layout):
+//   lfrom[nl] lto[nl] lcand[nl]  local end points / candidate record index
+//   adj_ptr[L+2] adj_item[2 nl]  per pose p: items l*2 + role (0 = from, 1 = to)
+//   ev_ptr[L+3]  ev_item[2 nl]   per index j: items l*2 + kind (0 = range start, 1 = one past its end)
+struct LoopTables {
+    std::vector<int> host;
+    int L = 0, nl = 0;
+    size_t size() const { return host.size(); }
+    static size_t capacity(int L, int nl) { return 7 * (size_t)nl + 2 * ((size_t)L + 2) + 8; }
+    void build(int lo, int hi, const std::vector<int>& members, const int* from, const int* to)
+    {
+        L = hi - lo; nl = (int)members.size();
+        host.assign(capacity(L, nl), 0);
+        int* lf = host.data();
+        int* lt = lf + nl;
+        int* lc = lt + nl;
+        int* adj_ptr = lc + nl;
+        int* adj_item = adj_ptr + (L + 2);
+        int* ev_ptr = adj_item + 2 * nl;
+        int* ev_item = ev_ptr + (L + 3);
+        for (int l = 0; l < nl; ++l) {
+            lf[l] = from[members[l]] - lo; lt[l] = to[members[l]] - lo; lc[l] = members[l];
+            ++adj_ptr[lf[l] + 1]; ++adj_ptr[lt[l] + 1];
+            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
+            ++ev_ptr[a + 1 + 1]; ++ev_ptr[b + 1 + 1];
+        }
+        for (int j = 0; j <= L; ++j) adj_ptr[j + 1] += adj_ptr[j];
+        for (int j = 0; j <= L + 1; ++j) ev_ptr[j + 1] += ev_ptr[j];
+        std::vector<int> ca(adj_ptr, adj_ptr + L + 1), ce(ev_ptr, ev_ptr + L + 2);
+        for (int l = 0; l < nl; ++l) {
+            adj_item[ca[lf[l]]++] = 2 * l;
+            adj_item[ca[lt[l]]++] = 2 * l + 1;
+            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
+            ev_item[ce[a + 1]++] = 2 * l;
+            ev_item[ce[b + 1]++] = 2 * l + 1;
+        }
+    }
+    // device pointers into a copy of `host` at d
+    const int* lfrom(const int* d) const { return d; }
+    const int* lto(const int* d) const { return d + nl; }
+    const int* lcand(const int* d) const { return d + 2 * nl; }
+    const int* adj_ptr(const int* d) const { return d + 3 * nl; }
+    const int* adj_item(const int* d) const { return adj_ptr(d) + (L + 2); }
+    const int* ev_ptr(const int* d) const { return adj_item(d) + 2 * nl; }
+    const int* ev_item(const int* d) const { return ev_ptr(d) + (L + 3); }
+};
+
+// Ops:  evaluate_committed(chi) | linearize(bb, bHb, hh, bh, info) | blend(alpha, c, bma)
+//       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
+template <class Ops>
+hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out)
+{
+    out = ClusterOut{};
+    double currentChi;
+    IPC_CL_CHK(ops.evaluate_committed(currentChi));
+    out.chi2_initial = currentChi;
+    double delta = 1e4;
+    const int maxTrials = 100;
+    for (int it = 0; it < iterations; ++it) {
+        double bb, bHb, hh, bh;
+        int info = 0;
+        IPC_CL_CHK(ops.linearize(bb, bHb, hh, bh, info));
+        if (info != 0) { out.flags |= 2; out.iterations = it + 1; break; }
+        const double hHh = bh;                        // H h_gn = b
+        const double alpha = bb / bHb, hsdNorm = std::sqrt(alpha * alpha * bb), hgnNorm = std::sqrt(hh);
+        bool goodStep = false;
+        int numTries = 0;
+        do {
+            ++numTries;
+            int stepType;
+            double beta = 0.0, sdScale = 0.0;
+            if (hgnNorm < delta) stepType = 0;
+            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
+            else {
+                stepType = 2;
+                double c, bma;
+                IPC_CL_CHK(ops.blend(alpha, c, bma));
+                const double hsdSq = alpha * alpha * bb;
+                if (c <= 0.) beta = (-c + std::sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
+                else beta = (delta * delta - hsdSq) / (c + std::sqrt(c * c + bma * (delta * delta - hsdSq)));
+            }
+            double pcoef, qcoef, hdlNorm;
+            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
+            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
+            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double bhdl = pcoef * bb + qcoef * bh;
+            double linearGain = -1 * hdlHhdl + 2 * bhdl;
+            double newChi;
+            bool anyChanged;
+            IPC_CL_CHK(ops.trial(pcoef, qcoef, newChi, anyChanged));
+            ++out.evals;
+            const double nonLinearGain = currentChi - newChi;
+            if (std::fabs(linearGain) < 1e-12) linearGain = 1e-12;
+            const double rho = nonLinearGain / linearGain;
+            if (rho > 0) {
+                goodStep = true;
+                currentChi = newChi;
+                ops.commit();
+            }
+            if (rho > 0.75) delta = std::max(delta, 3 * hdlNorm);
+            else if (rho < 0.25) delta *= 0.5;
+            if (!goodStep) {
+                if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                } else if (stepType == 1 && !anyChanged) {
+                    numTries = maxTrials;
+                }
+            }
+        } while (!goodStep && numTries < maxTrials);
+        out.iterations = it + 1;
+        out.tries += numTries;
+        if (numTries == maxTrials || !goodStep) { out.flags |= 1; break; }
+    }
+    IPC_CL_CHK(ops.max_edge_chi2(out.max_chi2));
+    out.chi2_total = currentChi;
+    return hipSuccess;
+}
+
+}  // namespace ipc

@@ -10,11 +10,7 @@
 // cross PCIe).  This mode is sequential by nature -- it is the reference's algorithm, not the
 // throughput path.
 #pragma once
-#include <algorithm>
-#include <cmath>
-#include <vector>
-
-#include "dense_chol.hpp"
+#include "cluster_common.hpp"
 #include "se2_cell.hpp"
 
 namespace ipc {
@@ -44,39 +40,6 @@ struct ClusterDev {
     double* scal;                            // [8] reduced scalars
     double* chi_edges;                       // [L + nl] per-edge chi2 (output)
 };
-
-constexpr int kGB = 256;                     // threads per block of the grid kernels
-
-template <int K>
-__device__ __forceinline__ void gk_block_reduce_store(double (&v)[K], double* partial_row)
-{
-    __shared__ double shm[K][kGB];
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < K; ++k) shm[k][t] = v[k];
-    __syncthreads();
-    for (int s = kGB / 2; s > 0; s >>= 1) {
-        if (t < s) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) shm[k][t] += shm[k][t + s];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) partial_row[k] = shm[k][0];
-    }
-}
-
-// sum of the per-block partials in block order (deterministic) -> scal[off + k]
-__global__ void gk_sum(const double* partial, int nblocks, int K, double* scal, int off)
-{
-    const int k = threadIdx.x;
-    if (k >= K) return;
-    double acc = 0.0;
-    for (int bq = 0; bq < nblocks; ++bq) acc += partial[bq * 4 + k];
-    scal[off + k] = acc;
-}
 
 __device__ __forceinline__ Pose2 gk_pose(const PoseArr& A, int p)
 {
@@ -234,31 +197,6 @@ __global__ void gk_bHb_psi(ClusterDev D)
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
-// in-place inclusive prefix sums over indices 1..L of K arrays (row length ld), one workgroup
-__global__ __launch_bounds__(1024) void gk_scan(double* arr, int K, int L, int ld)
-{
-    __shared__ double wsum[16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int k = 0; k < K; ++k) {
-        double* a = arr + (size_t)k * ld;
-        double carry = 0.0;
-        for (int base = 1; base <= L; base += 1024) {
-            const int i = base + tid;
-            double v = i <= L ? a[i] : 0.0;
-            v = wave_inclusive_scan(v);
-            if (lane == 63) wsum[wave] = v;
-            __syncthreads();
-            double off = carry;
-            for (int w = 0; w < wave; ++w) off += wsum[w];
-            double tot = carry;
-            for (int w = 0; w < 16; ++w) tot += wsum[w];
-            if (i <= L) a[i] = v + off;
-            carry = tot;
-            __syncthreads();
-        }
-    }
-}
-
 // capacitance system: S (lower triangle, column major) and rhs
 __global__ void gk_assemble(ClusterDev D)
 {
@@ -413,11 +351,6 @@ __global__ void gk_update(ClusterDev D, double p, double q)
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-struct ClusterOut {
-    double max_chi2 = 0.0, chi2_total = 0.0, chi2_initial = 0.0;
-    int iterations = 0, tries = 0, flags = 0, evals = 0;    // flags: 1 terminated, 2 solve failed
-};
-
 class ClusterSolver2 {
 public:
     ~ClusterSolver2() { release(); }
@@ -431,13 +364,24 @@ public:
                      const int* to, int iterations, ClusterOut& out, std::vector<double>* chi_host);
     const PoseArr& result() const { return dev_.X; }
 
+    // ---- Ops of cluster_dogleg ----
+    hipError_t evaluate_committed(double& chi) { return evaluate(dev_.X, dev_.e, dev_.le, chi); }
+    hipError_t linearize(double& bb, double& bHb, double& hh, double& bh, int& info);
+    hipError_t blend(double alpha, double& c, double& bma);
+    hipError_t trial(double p, double q, double& newChi, bool& anyChanged);
+    void commit() { std::swap(dev_.X, dev_.Xn); std::swap(dev_.e, dev_.en); std::swap(dev_.le, dev_.len); }
+    hipError_t max_edge_chi2(double& mx);
+
 private:
     ClusterDev dev_{};
+    hipStream_t st_ = nullptr;
+    int nblk_ = 1;
+    std::vector<double>* chi_host_ = nullptr;
     int capL_ = 0, capNl_ = 0;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_partial_ = nullptr, *d_scal_ = nullptr;
     int *d_int_ = nullptr, *d_info_ = nullptr;
-    double* h_scal_ = nullptr;          // pinned [8] + info
-    std::vector<int> h_int_;
+    double* h_scal_ = nullptr;          // pinned [12] + info
+    LoopTables tab_;
 
     void release()
     {
@@ -448,9 +392,25 @@ private:
         capL_ = capNl_ = 0;
     }
     hipError_t ensure(int L, int nl);
+    hipError_t fetch(int n)
+    {
+        IPC_CL_CHK(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double) * n, hipMemcpyDeviceToHost, st_));
+        IPC_CL_CHK(hipMemcpyAsync(h_scal_ + 12, d_info_, sizeof(int), hipMemcpyDeviceToHost, st_));
+        return hipStreamSynchronize(st_);
+    }
+    void sum_partials(int K, int off)
+    {
+        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st_, (const double*)dev_.partial, nblk_, K, dev_.scal, off);
+    }
+    hipError_t evaluate(const PoseArr& Y, double* eo, double* leo, double& chi)
+    {
+        hipLaunchKernelGGL(gk_eval, dim3(nblk_), dim3(kGB), 0, st_, dev_, Y, eo, leo);
+        sum_partials(1, 7);
+        IPC_CL_CHK(fetch(8));
+        chi = h_scal_[7];
+        return hipSuccess;
+    }
 };
-
-#define IPC_CL_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 inline hipError_t ClusterSolver2::ensure(int L, int nl)
 {
@@ -469,9 +429,73 @@ inline hipError_t ClusterSolver2::ensure(int L, int nl)
         IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (27 * (size_t)nN + 8)));
         IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * (3 * (size_t)nN + 1) * (3 * (size_t)nN)));
         IPC_CL_CHK(hipMalloc(&d_partial_, sizeof(double) * 4 * ((nL + nN + 1 + kGB) / kGB + 1)));
-        IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * (7 * (size_t)nN + 2 * ld + 8)));
+        IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
         capL_ = nL; capNl_ = nN;
     }
+    return hipSuccess;
+}
+
+inline hipError_t ClusterSolver2::linearize(double& bb, double& bHb, double& hh, double& bh, int& info)
+{
+    ClusterDev& D = dev_;
+    const dim3 grid(nblk_), block(kGB);
+    const int L = D.L, nl = D.nl, ld = D.ld;
+    hipLaunchKernelGGL(gk_force, grid, block, 0, st_, D);
+    hipLaunchKernelGGL(gk_b, grid, block, 0, st_, D);
+    sum_partials(1, 0);
+    hipLaunchKernelGGL(gk_bHb_psi, grid, block, 0, st_, D);
+    sum_partials(1, 1);
+    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.ps, 9, L, ld);
+    hipLaunchKernelGGL(gk_assemble, dim3((nl + 63) / 64, nl), dim3(64), 0, st_, D);
+    IPC_CL_CHK(chol_solve_device(D.S, 3 * nl, D.rhs, d_info_, st_));
+    hipLaunchKernelGGL(gk_nu, dim3((nl + 63) / 64), dim3(64), 0, st_, D);
+    hipLaunchKernelGGL(gk_events, dim3((L + 2 + kGB - 1) / kGB), block, 0, st_, D);
+    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.nd, 3, L, ld);
+    hipLaunchKernelGGL(gk_rho, grid, block, 0, st_, D);
+    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.sc, 1, L, ld);
+    hipLaunchKernelGGL(gk_term, grid, block, 0, st_, D);
+    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.sc + ld, 2, L, ld);
+    hipLaunchKernelGGL(gk_h, grid, block, 0, st_, D);
+    sum_partials(2, 2);
+    IPC_CL_CHK(hipGetLastError());
+    IPC_CL_CHK(fetch(4));
+    std::memcpy(&info, h_scal_ + 12, sizeof(int));
+    bb = h_scal_[0]; bHb = h_scal_[1]; hh = h_scal_[2]; bh = h_scal_[3];
+    return hipSuccess;
+}
+
+inline hipError_t ClusterSolver2::blend(double alpha, double& c, double& bma)
+{
+    hipLaunchKernelGGL(gk_blend, dim3(nblk_), dim3(kGB), 0, st_, dev_, alpha);
+    sum_partials(2, 4);
+    IPC_CL_CHK(fetch(6));
+    c = h_scal_[4]; bma = h_scal_[5];
+    return hipSuccess;
+}
+
+inline hipError_t ClusterSolver2::trial(double p, double q, double& newChi, bool& anyChanged)
+{
+    hipLaunchKernelGGL(gk_update, dim3(nblk_), dim3(kGB), 0, st_, dev_, p, q);
+    sum_partials(1, 6);
+    IPC_CL_CHK(evaluate(dev_.Xn, dev_.en, dev_.len, newChi));
+    anyChanged = h_scal_[6] != 0.0;
+    return hipSuccess;
+}
+
+inline hipError_t ClusterSolver2::max_edge_chi2(double& mx_out)
+{
+    ClusterDev& D = dev_;
+    hipLaunchKernelGGL(gk_chi_edges, dim3(nblk_), dim3(kGB), 0, st_, D);
+    IPC_CL_CHK(hipGetLastError());
+    std::vector<double> local;
+    std::vector<double>& chi = chi_host_ ? *chi_host_ : local;
+    chi.resize((size_t)D.L + D.nl);
+    IPC_CL_CHK(hipMemcpyAsync(chi.data(), D.chi_edges, sizeof(double) * chi.size(), hipMemcpyDeviceToHost, st_));
+    IPC_CL_CHK(hipStreamSynchronize(st_));
+    double mx = 0.0;
+    bool nan = false;
+    for (double c : chi) { if (c != c) nan = true; else mx = std::max(mx, c); }
+    mx_out = nan ? std::nan("") : mx;
     return hipSuccess;
 }
 
@@ -483,6 +507,7 @@ inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int
     const int L = hi - lo, nl = (int)members.size(), NS = 3 * nl;
     IPC_CL_CHK(ensure(L, nl));
     const int ld = L + 2;
+    st_ = st; chi_host_ = chi_host;
     ClusterDev& D = dev_;
     D.chain = chain; D.estride = estride; D.lo = lo; D.L = L; D.nl = nl; D.ld = ld;
     D.cand = cand; D.cstride = cstride;
@@ -501,155 +526,19 @@ inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int
         D.S = d_S_; D.ldS = NS + 1;
         D.partial = d_partial_; D.scal = d_scal_;
     }
-    {   // loop tables: local endpoints, per-pose adjacency, per-index range events
-        h_int_.assign(7 * (size_t)nl + 2 * (size_t)ld + 8, 0);
-        int* lf = h_int_.data();
-        int* lt = lf + nl;
-        int* lc = lt + nl;
-        int* adj_ptr = lc + nl;            // [L+2]
-        int* adj_item = adj_ptr + (L + 2); // [2 nl]
-        int* ev_ptr = adj_item + 2 * nl;   // [L+3]
-        int* ev_item = ev_ptr + (L + 3);   // [2 nl]
-        for (int l = 0; l < nl; ++l) {
-            lf[l] = from[members[l]] - lo; lt[l] = to[members[l]] - lo; lc[l] = members[l];
-            ++adj_ptr[lf[l] + 1]; ++adj_ptr[lt[l] + 1];
-            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
-            ++ev_ptr[a + 1 + 1]; ++ev_ptr[b + 1 + 1];
-        }
-        for (int j = 0; j <= L; ++j) adj_ptr[j + 1] += adj_ptr[j];
-        for (int j = 0; j <= L + 1; ++j) ev_ptr[j + 1] += ev_ptr[j];
-        std::vector<int> ca(adj_ptr, adj_ptr + L + 1), ce(ev_ptr, ev_ptr + L + 2);
-        for (int l = 0; l < nl; ++l) {
-            adj_item[ca[lf[l]]++] = 2 * l;
-            adj_item[ca[lt[l]]++] = 2 * l + 1;
-            const int a = std::min(lf[l], lt[l]), b = std::max(lf[l], lt[l]);
-            ev_item[ce[a + 1]++] = 2 * l;
-            ev_item[ce[b + 1]++] = 2 * l + 1;
-        }
-        IPC_CL_CHK(hipMemcpyAsync(d_int_, h_int_.data(), sizeof(int) * h_int_.size(), hipMemcpyHostToDevice, st));
-        IPC_CL_CHK(hipStreamSynchronize(st));       // h_int_ is pageable and reused
-        D.lfrom = d_int_; D.lto = d_int_ + nl; D.lcand = d_int_ + 2 * nl;
-        D.adj_ptr = d_int_ + 3 * nl; D.adj_item = D.adj_ptr + (L + 2);
-        D.ev_ptr = D.adj_item + 2 * nl; D.ev_item = D.ev_ptr + (L + 3);
-    }
+    tab_.build(lo, hi, members, from, to);
+    IPC_CL_CHK(hipMemcpyAsync(d_int_, tab_.host.data(), sizeof(int) * tab_.size(), hipMemcpyHostToDevice, st));
+    IPC_CL_CHK(hipStreamSynchronize(st));           // the host table is pageable and reused
+    D.lfrom = tab_.lfrom(d_int_); D.lto = tab_.lto(d_int_); D.lcand = tab_.lcand(d_int_);
+    D.adj_ptr = tab_.adj_ptr(d_int_); D.adj_item = tab_.adj_item(d_int_);
+    D.ev_ptr = tab_.ev_ptr(d_int_); D.ev_item = tab_.ev_item(d_int_);
     const double* sp[5] = {src.x, src.y, src.th, src.c, src.s};
     double* xp[5] = {D.X.x, D.X.y, D.X.th, D.X.c, D.X.s};
     for (int k = 0; k < 5; ++k)
         IPC_CL_CHK(hipMemcpyAsync(xp[k], sp[k] + lo, sizeof(double) * (L + 1), hipMemcpyDeviceToDevice, st));
-
-    const int nblk = (L + nl + 1 + kGB - 1) / kGB;      // indices 0 .. L+nl
-    const dim3 grid(nblk), block(kGB);
-    auto fetch = [&](int n) -> hipError_t {
-        IPC_CL_CHK(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-        IPC_CL_CHK(hipMemcpyAsync(h_scal_ + 12, d_info_, sizeof(int), hipMemcpyDeviceToHost, st));
-        return hipStreamSynchronize(st);
-    };
-    auto evaluate = [&](const PoseArr& Y, double* eo, double* leo, double& chi) -> hipError_t {
-        hipLaunchKernelGGL(gk_eval, grid, block, 0, st, D, Y, eo, leo);
-        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 7);
-        IPC_CL_CHK(fetch(8));
-        chi = h_scal_[7];
-        return hipSuccess;
-    };
-
-    out = ClusterOut{};
-    double currentChi;
+    nblk_ = (L + nl + 1 + kGB - 1) / kGB;            // indices 0 .. L+nl
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
-    IPC_CL_CHK(evaluate(D.X, D.e, D.le, currentChi));
-    out.chi2_initial = currentChi;
-    double delta = 1e4;
-    const int maxTrials = 100;
-    for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(gk_force, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_b, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 0);
-        hipLaunchKernelGGL(gk_bHb_psi, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 1);
-        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.ps, 9, L, ld);
-        hipLaunchKernelGGL(gk_assemble, dim3((nl + 63) / 64, nl), dim3(64), 0, st, D);
-        IPC_CL_CHK(chol_solve_device(D.S, NS, D.rhs, d_info_, st));
-        hipLaunchKernelGGL(gk_nu, dim3((nl + 63) / 64), dim3(64), 0, st, D);
-        hipLaunchKernelGGL(gk_events, dim3((L + 2 + kGB - 1) / kGB), block, 0, st, D);
-        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.nd, 3, L, ld);
-        hipLaunchKernelGGL(gk_rho, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.sc, 1, L, ld);
-        hipLaunchKernelGGL(gk_term, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st, D.sc + ld, 2, L, ld);
-        hipLaunchKernelGGL(gk_h, grid, block, 0, st, D);
-        hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 2, D.scal, 2);
-        IPC_CL_CHK(hipGetLastError());
-        IPC_CL_CHK(fetch(4));
-        int info;
-        std::memcpy(&info, h_scal_ + 12, sizeof(int));
-        if (info != 0) { out.flags |= 2; out.iterations = it + 1; break; }
-        const double bb = h_scal_[0], bHb = h_scal_[1], bh = h_scal_[3], hHh = bh;
-        const double alpha = bb / bHb, hsdNorm = std::sqrt(alpha * alpha * bb), hgnNorm = std::sqrt(h_scal_[2]);
-        bool goodStep = false;
-        int numTries = 0;
-        do {
-            ++numTries;
-            int stepType;
-            double beta = 0.0, sdScale = 0.0;
-            if (hgnNorm < delta) stepType = 0;
-            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
-            else {
-                stepType = 2;
-                hipLaunchKernelGGL(gk_blend, grid, block, 0, st, D, alpha);
-                hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 2, D.scal, 4);
-                IPC_CL_CHK(fetch(6));
-                const double c = h_scal_[4], bma = h_scal_[5], hsdSq = alpha * alpha * bb;
-                if (c <= 0.) beta = (-c + std::sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
-                else beta = (delta * delta - hsdSq) / (c + std::sqrt(c * c + bma * (delta * delta - hsdSq)));
-            }
-            double pcoef, qcoef, hdlNorm;
-            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
-            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
-            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
-            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
-            const double bhdl = pcoef * bb + qcoef * bh;
-            double linearGain = -1 * hdlHhdl + 2 * bhdl;
-            hipLaunchKernelGGL(gk_update, grid, block, 0, st, D, pcoef, qcoef);
-            hipLaunchKernelGGL(gk_sum, dim3(1), dim3(64), 0, st, (const double*)D.partial, nblk, 1, D.scal, 6);
-            double newChi;
-            IPC_CL_CHK(evaluate(D.Xn, D.en, D.len, newChi));
-            const bool anyChanged = h_scal_[6] != 0.0;
-            ++out.evals;
-            const double nonLinearGain = currentChi - newChi;
-            if (std::fabs(linearGain) < 1e-12) linearGain = 1e-12;
-            const double rho = nonLinearGain / linearGain;
-            if (rho > 0) {
-                goodStep = true;
-                currentChi = newChi;
-                std::swap(D.X, D.Xn); std::swap(D.e, D.en); std::swap(D.le, D.len);
-            }
-            if (rho > 0.75) delta = std::max(delta, 3 * hdlNorm);
-            else if (rho < 0.25) delta *= 0.5;
-            if (!goodStep) {
-                if (stepType == 0) {
-                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
-                } else if (stepType == 1 && !anyChanged) {
-                    numTries = maxTrials;
-                }
-            }
-        } while (!goodStep && numTries < maxTrials);
-        out.iterations = it + 1;
-        out.tries += numTries;
-        if (numTries == maxTrials || !goodStep) { out.flags |= 1; break; }
-    }
-    // per-edge chi2 of the committed state
-    hipLaunchKernelGGL(gk_chi_edges, grid, block, 0, st, D);
-    IPC_CL_CHK(hipGetLastError());
-    std::vector<double> local;
-    std::vector<double>& chi = chi_host ? *chi_host : local;
-    chi.resize((size_t)L + nl);
-    IPC_CL_CHK(hipMemcpyAsync(chi.data(), D.chi_edges, sizeof(double) * chi.size(), hipMemcpyDeviceToHost, st));
-    IPC_CL_CHK(hipStreamSynchronize(st));
-    double mx = 0.0;
-    bool nan = false;
-    for (double c : chi) { if (c != c) nan = true; else mx = std::max(mx, c); }
-    out.max_chi2 = nan ? std::nan("") : mx;
-    out.chi2_total = currentChi;
-    return hipSuccess;
+    return cluster_dogleg(*this, iterations, out);
 }
 
 }  // namespace ipc

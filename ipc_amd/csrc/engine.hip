@@ -21,6 +21,7 @@
 #include "../../include/ipc_amd.h"
 #include "cell_kernels.hpp"
 #include "cluster_se2.hpp"
+#include "cluster_se3.hpp"
 
 using namespace ipc;
 
@@ -151,7 +152,8 @@ __device__ void inv_sym6(const double* up, double* out)      // 21 upper -> 21 u
         }
 }
 
-__global__ void k_se3_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride)
+__global__ void k_se3_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
+                           double unscale = 1.0)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -162,7 +164,7 @@ __global__ void k_se3_prep(int n, const double* meas, const double* info, double
     for (int q = 0; q < 9; ++q) rec[(size_t)(G_RZ + q) * stride + k] = R[q];
     for (int q = 0; q < 3; ++q) rec[(size_t)(G_TZ + q) * stride + k] = m[q];
     double om[21], sg[21];
-    for (int q = 0; q < 21; ++q) om[q] = info[21 * (size_t)k + q] * scale;
+    for (int q = 0; q < 21; ++q) om[q] = unscale == 1.0 ? info[21 * (size_t)k + q] * scale : (info[21 * (size_t)k + q] * scale) / unscale;
     inv_sym6(om, sg);
     for (int q = 0; q < 21; ++q) {
         rec[(size_t)(G_OM + q) * stride + k] = om[q];
@@ -395,6 +397,7 @@ struct ipc_engine {
     double* d_open = nullptr;                          // [5][V] open-loop x y th cos sin
     double* d_cur = nullptr;                           // [5][V] current estimates
     ClusterSolver2* cluster = nullptr;
+    ClusterSolver3* cluster3 = nullptr;                // SE3: d_open is d_pose0 itself, d_cur is [12][V]
 };
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
@@ -477,8 +480,9 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
-    hipFree(h->d_chain1); hipFree(h->d_open); hipFree(h->d_cur);
+    hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
     delete h->cluster;
+    delete h->cluster3;
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -497,7 +501,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     h->cns.clear();
     h->h_from.clear(); h->h_to.clear();
     if (h->d_cur && h->d_open)
-        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
@@ -821,6 +825,26 @@ __global__ void k_se2_propagate_tail(int V, int start, const double* rec, int st
     }
 }
 
+// SE3 propagateCurrentGuess: v[i] = v[i-1] * z[i-1] (Isometry3 product) for i = start+1 .. V-1
+__global__ void k_se3_propagate_tail(int V, int start, const double* rec, int stride, double* cur)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double R[9], t[3];
+    for (int q = 0; q < 9; ++q) R[q] = cur[(size_t)q * V + start];
+    for (int q = 0; q < 3; ++q) t[q] = cur[(size_t)(9 + q) * V + start];
+    for (int i = start + 1; i < V; ++i) {
+        double Rz[9], tz[3], Rn[9], d[3];
+        for (int q = 0; q < 9; ++q) Rz[q] = rec[(size_t)(G_RZ + q) * stride + i - 1];
+        for (int q = 0; q < 3; ++q) tz[q] = rec[(size_t)(G_TZ + q) * stride + i - 1];
+        m3_mul(R, Rz, Rn);
+        m3_vec(R, tz, d);
+        for (int q = 0; q < 3; ++q) t[q] += d[q];
+        for (int q = 0; q < 9; ++q) R[q] = Rn[q];
+        for (int q = 0; q < 9; ++q) cur[(size_t)q * V + i] = R[q];
+        for (int q = 0; q < 3; ++q) cur[(size_t)(9 + q) * V + i] = t[q];
+    }
+}
+
 static PoseArr pose_arr(double* base, int V)
 {
     return PoseArr{base, base + (size_t)V, base + 2 * (size_t)V, base + 3 * (size_t)V, base + 4 * (size_t)V};
@@ -828,8 +852,17 @@ static PoseArr pose_arr(double* base, int V)
 
 static int ensure_incremental(ipc_engine* h, const char* who)
 {
-    if (h->dim != 2) return fail(IPC_ERR_LIMIT, "%s: the incremental / final-map mode is SE2 only in this build", who);
+    (void)who;
     HIPCHK(hipSetDevice(h->device));
+    if (h->dim == 3) {
+        if (!h->d_cur) {
+            h->d_open = h->d_pose0;                   // same [12][V] layout; not owned twice, see ipc_destroy
+            HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 12 * (size_t)h->V));
+            HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
+        }
+        if (!h->cluster3) h->cluster3 = new ClusterSolver3();
+        return IPC_OK;
+    }
     if (!h->d_open) {
         HIPCHK(hipMalloc(&h->d_open, sizeof(double) * 5 * (size_t)h->V));
         HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 5 * (size_t)h->V));
@@ -854,7 +887,7 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_reset: NULL handle");
     if (int rc = ensure_incremental(h, "ipc_incremental_reset")) return rc;
-    HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
     h->cns.clear();
     return IPC_OK;
 }
@@ -889,6 +922,25 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
     members.push_back(k);                                                     // :56
     if ((hi - lo) + (int)members.size() > 100) iters *= 5;                   // consensus_utils.cpp:12-13
     ClusterOut o;
+    if (h->dim == 3) {
+        HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V,
+                                  lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
+        const bool agree3 = !(o.max_chi2 > th);
+        if (agree3) {
+            HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, h->cluster3->result(),
+                                    sizeof(double) * h->cluster3->ld(), sizeof(double) * (hi - lo + 1), 12,
+                                    hipMemcpyDeviceToDevice, h->own_stream));
+            if (hi + 1 < h->V)
+                hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, h->own_stream, h->V, hi, h->d_chain,
+                                   h->estride, h->d_cur);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->own_stream));
+            h->cns.push_back(k);
+        }
+        *agrees = agree3 ? 1 : 0;
+        fill_info(info, lo, hi, nclu, o);
+        return IPC_OK;
+    }
     HIPCHK(h->cluster->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, pose_arr(h->d_cur, h->V),
                              lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
     const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
@@ -963,10 +1015,21 @@ static int download_poses(ipc_engine* h, const PoseArr& X, int n, double* poses_
     return IPC_OK;
 }
 
+// SE3: device [12][ld] (first n columns) -> host [n][12]
+static int download_poses3(ipc_engine* h, const double* d, int ld, int n, double* poses_out)
+{
+    std::vector<double> tmp(12 * (size_t)n);
+    HIPCHK(hipMemcpy2D(tmp.data(), sizeof(double) * n, d, sizeof(double) * ld, sizeof(double) * n, 12, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+        for (int f = 0; f < 12; ++f) poses_out[12 * (size_t)i + f] = tmp[(size_t)f * n + i];
+    return IPC_OK;
+}
+
 extern "C" int ipc_current_poses(ipc_engine_t* h, double* poses_out)
 {
     if (!h || !poses_out) return fail(IPC_ERR_ARG, "ipc_current_poses: NULL argument");
     if (int rc = ensure_incremental(h, "ipc_current_poses")) return rc;
+    if (h->dim == 3) return download_poses3(h, h->d_cur, h->V, h->V, poses_out);
     return download_poses(h, pose_arr(h->d_cur, h->V), h->V, poses_out);
 }
 
@@ -979,14 +1042,20 @@ extern "C" int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int 
     const int E = h->V - 1;
     if (!h->d_chain1) {
         double *d_m = nullptr, *d_i = nullptr;
-        HIPCHK(hipMalloc(&h->d_chain1, sizeof(double) * F_NFIELDS * h->estride));
-        HIPCHK(hipMalloc(&d_m, sizeof(double) * 3 * E));
-        HIPCHK(hipMalloc(&d_i, sizeof(double) * 6 * E));
-        HIPCHK(hipMemcpy(d_m, h->h_odom_meas.data(), sizeof(double) * 3 * E, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_i, h->h_odom_info.data(), sizeof(double) * 6 * E, hipMemcpyHostToDevice));
-        HIPCHK(hipMemsetAsync(h->d_chain1, 0, sizeof(double) * F_NFIELDS * h->estride, h->own_stream));
-        hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
-                           h->prm.s_factor, h->d_chain1, h->estride, h->prm.s_factor);
+        const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
+        const size_t nf = h->dim == 2 ? (size_t)F_NFIELDS : (size_t)G_NFIELDS;
+        HIPCHK(hipMalloc(&h->d_chain1, sizeof(double) * (nf * h->estride + 64)));
+        HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * E));
+        HIPCHK(hipMalloc(&d_i, sizeof(double) * is * E));
+        HIPCHK(hipMemcpy(d_m, h->h_odom_meas.data(), sizeof(double) * ms * E, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_i, h->h_odom_info.data(), sizeof(double) * is * E, hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(h->d_chain1, 0, sizeof(double) * (nf * h->estride + 64), h->own_stream));
+        if (h->dim == 2)
+            hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
+                               h->prm.s_factor, h->d_chain1, h->estride, h->prm.s_factor);
+        else
+            hipLaunchKernelGGL(k_se3_prep, dim3((E + 63) / 64), dim3(64), 0, h->own_stream, E, d_m, d_i,
+                               h->prm.s_factor, h->d_chain1, h->estride, h->prm.s_factor);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->own_stream));
         HIPCHK(hipFree(d_m));
@@ -998,10 +1067,18 @@ extern "C" int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int 
         // pure odometry: the open-loop guess already has zero error, optimize() leaves it alone
         ClusterOut o;
         fill_info(info, 0, h->V - 1, 0, o);
+        if (poses_out && h->dim == 3) return download_poses3(h, h->d_open, h->V, h->V, poses_out);
         if (poses_out) return download_poses(h, pose_arr(h->d_open, h->V), h->V, poses_out);
         return IPC_OK;
     }
     ClusterOut o;
+    if (h->dim == 3) {
+        HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain1, h->estride, h->d_cand, h->cstride, h->d_open, h->V,
+                                  0, h->V - 1, members, h->h_from.data(), h->h_to.data(), iterations, o, nullptr));
+        fill_info(info, 0, h->V - 1, (int)members.size(), o);
+        if (poses_out) return download_poses3(h, h->cluster3->result(), h->cluster3->ld(), h->V, poses_out);
+        return IPC_OK;
+    }
     HIPCHK(h->cluster->solve(h->own_stream, h->d_chain1, h->estride, h->d_cand, h->cstride, pose_arr(h->d_open, h->V),
                              0, h->V - 1, members, h->h_from.data(), h->h_to.data(), iterations, o, nullptr));
     fill_info(info, 0, h->V - 1, (int)members.size(), o);

@@ -243,7 +243,7 @@ void IPC::addEdgeToCnS(int k)
 
 std::vector<double> IPC::finalMap(const std::vector<uint8_t>& accepted, int iterations, double* chi2_out)
 {
-    std::vector<double> out((size_t)_V * 3);
+    std::vector<double> out((size_t)_V * (_dim == 2 ? 3 : 12));
     ipc_check_info_t info{};
     check(ipc_final_optimize(_h, accepted.data(), iterations, out.data(), &info));
     if (chi2_out) *chi2_out = info.chi2_total;
@@ -323,9 +323,8 @@ SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph&
     std::cout << "Recall = " << r.recall << std::endl;
 
     // Trajectory file: the poses after the final optimize(1000) over odometry/s + accepted loops
-    // (simulation.cpp:50-65).  SE3 (final map not built yet) writes the
-    // open-loop (propagateGuess) poses.
-    const std::vector<double> poses = g.dim == 2 ? ipc.finalMap(bucket, 1000, &r.final_chi2) : ipc.initialPoses();
+    // (simulation.cpp:50-65)
+    const std::vector<double> poses = ipc.finalMap(bucket, 1000, &r.final_chi2);
     const int ps = g.dim == 2 ? 3 : 12;
     std::ofstream outfile(cfg.output.c_str());
     for (int i = 0; i < ipc.numVertices(); ++i) write_pose(outfile, g.dim, &poses[(size_t)i * ps]);

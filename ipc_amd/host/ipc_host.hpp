@@ -62,7 +62,7 @@ public:
     // Batched form of the per-candidate agreementCheck loop (src/simulation.cpp:34-47): returns,
     // per candidate (file order), whether it is in the consensus set.
     std::vector<uint8_t> agreementCheckAll(const std::vector<Edge>& candidates);
-    // The reference's own per-candidate interface (faithful incremental mode, SE2):
+    // The reference's own per-candidate interface (faithful incremental mode):
     // setCandidates uploads the list once, then agreementCheck(k) is IPC::agreementCheck
     // (src/consensus.cpp:43-75) for candidate k (index into that list).
     void setCandidates(const std::vector<Edge>& candidates);
@@ -70,7 +70,7 @@ public:
     bool removeEdgeFromCnS(int k);                      // src/consensus.cpp:77-96
     void addEdgeToCnS(int k);                           // src/consensus.cpp:98-119
     // Final map of the harness (src/simulation.cpp:50-65): optimize(iterations) over odometry with
-    // its information back to (info*s)/s plus the accepted candidates; SE2 [V][3].
+    // its information back to (info*s)/s plus the accepted candidates; [V][3] or [V][12].
     std::vector<double> finalMap(const std::vector<uint8_t>& accepted, int iterations = 1000,
                                  double* chi2_out = nullptr);
     // candidate indices in acceptance order (reference getMaxConsensusSet, consensus.hpp:16)
@@ -98,10 +98,10 @@ struct SimulationResult {
 
 // The harness: labels the first cfg.canonic_inliers loops as inliers (src/simulation.cpp:24-25),
 // runs the consensus, prints the reference's console lines, writes cfg.output (trajectory after
-// the final map optimisation for SE2; open-loop poses for SE3) and "<output minus 3 chars>PR"
+// the final map optimisation) and "<output minus 3 chars>PR"
 // (src/simulation.cpp:91-105).  Environment IPC_AMD_MODE selects the consensus formulation:
 // "matrix" (default: batched consistency matrix + set-max) or "incremental" (the reference's
-// per-candidate agreementCheck loop on the GPU, SE2 only).
+// per-candidate agreementCheck loop on the GPU).
 SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph& g, const std::vector<Edge>& odom,
                                              const std::vector<Edge>& loops, int device = 0);
 

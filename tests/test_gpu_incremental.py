@@ -130,9 +130,71 @@ def test_final_map_without_loops_is_open_loop(oracle):
     assert info.chi2_total == 0.0
 
 
-def test_incremental_is_se2_only_for_now():
-    from ipc_amd import capi, synth
-    g = synth.small_se3()
-    eng, _ = _engine(g, s_factor=50.0)
-    with pytest.raises(capi.IpcError, match="SE2 only"):
-        eng.reset()
+# ---- SE3 ---------------------------------------------------------------------------------
+def _rot_angle(Ra, Rb):
+    """Angle of Ra^T Rb for [n, 9] row-major rotations."""
+    A, B = Ra.reshape(-1, 3, 3), Rb.reshape(-1, 3, 3)
+    tr = np.einsum("nij,nij->n", A, B)
+    return np.arccos(np.clip((tr - 1.0) / 2.0, -1.0, 1.0))
+
+
+def _run_both_se3(O, g, eng, cfg):
+    inc = O.IncrementalIPC(3, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th,
+                           cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base,
+                           g.loop_ids, g.loop_meas, g.loop_info)
+    eng.reset()
+    for k in eng.candidate_order():
+        ok_ref, ref = inc.agreement_check(k)
+        ok, info = eng.agreementCheck(k, with_info=True)
+        assert (info.lo, info.hi, info.n_cluster_loops) == (ref["lo"], ref["hi"], ref["cluster"]), (k, ref)
+        assert ok == ok_ref, (k, ref, info.max_chi2)
+        err = abs(info.max_chi2 - ref["max_chi2"]) / max(abs(ref["max_chi2"]), 1e-12)
+        assert err <= REL, (k, ref, info.max_chi2)
+    assert np.array_equal(eng.getMaxConsensusSet(), inc.consensus())
+    ref_poses, got = inc.poses(), eng.current_poses()
+    assert np.allclose(got[:, 9:], ref_poses[:, 9:], rtol=0, atol=1e-6)
+    assert _rot_angle(got[:, :9], ref_poses[:, :9]).max() <= 1e-6
+    return inc
+
+
+def test_incremental_se3_small_step_by_step(oracle):
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth.small_se3(), 5, seed=4)
+    eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+    _run_both_se3(oracle, g, eng, cfg)
+
+
+def test_incremental_se3_clusters(oracle):
+    """A small sphere: clusters absorb several accepted loops (12 x 12 and larger capacitance systems)."""
+    from ipc_amd import synth
+    g = synth.sphere_like(rings=8, per_ring=16, radius=8.0)
+    keep = np.arange(0, g.N, max(1, g.N // 24))
+    g = synth.inject_outliers(g.subset(keep), 8, seed=6)
+    eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+    inc = _run_both_se3(oracle, g, eng, cfg)
+    assert len(inc.consensus()) >= 5
+
+
+def test_final_map_se3_matches_oracle(oracle):
+    from ipc_amd import synth
+    O = oracle
+    g = synth.sphere_like(rings=8, per_ring=16, radius=8.0)
+    keep = np.arange(0, g.N, max(1, g.N // 24))
+    g = synth.inject_outliers(g.subset(keep), 6, seed=3)
+    eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+    _, acc = eng.run()
+    assert acc.sum() >= 3
+    s = cfg.s_factor
+    info = (np.asarray(g.odom_info) * s) / s
+    poses0 = O.propagate(3, g.odom_meas)
+    sel = [k for k in O.candidate_order(g.loop_ids) if acc[k]]
+    n_edges = (g.V - 1) + len(sel)
+    iters = 1000
+    base = iters // 5 if n_edges > 100 else iters
+    ref = O.solve_cell(3, g.odom_meas, info, 1.0, poses0, 0, g.V - 1, g.loop_ids[sel], g.loop_meas[sel],
+                       g.loop_info[sel], base, want_poses=True)
+    poses, inf = eng.final_optimize(acc, iterations=iters)
+    assert abs(inf.chi2_total - ref["chi2_final"]) <= REL * max(ref["chi2_final"], 1e-12)
+    assert abs(inf.max_chi2 - ref["max_chi2"]) <= REL * max(ref["max_chi2"], 1e-12)
+    assert np.allclose(poses[:, 9:], ref["poses"][:, 9:], rtol=0, atol=1e-6)
+    assert _rot_angle(poses[:, :9], ref["poses"][:, :9]).max() <= 1e-6

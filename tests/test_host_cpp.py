@@ -123,16 +123,25 @@ def test_tester_outputs_match_python_path(built, tmp_path, dim):
     traj = np.loadtxt(str(tmp_path / "res.txt"))
     assert traj.shape[1] == (3 if dim == 2 else 7)
     assert np.allclose(traj[0][:3], 0)
+    # the trajectory is the final map (reference src/simulation.cpp:50-65,91-98); the file
+    # carries operator<<'s 6 significant digits
+    from ipc_amd import graphio
+    from ipc_amd.consensus import IPC, Config
+    g = graphio.read_g2o(vals["dataset"])
+    eng = IPC(g, Config(vals["fth"], 50, vals["sth"], 100, vals["s"]))
+    poses, _ = eng.final_optimize(acc)
     if dim == 2:
-        # the trajectory is the final map (reference src/simulation.cpp:50-65,91-98); the file
-        # carries operator<<'s 6 significant digits
-        from ipc_amd import graphio
-        from ipc_amd.consensus import IPC, Config
-        g = graphio.read_g2o(vals["dataset"])
-        eng = IPC(g, Config(vals["fth"], 50, vals["sth"], 100, vals["s"]))
-        poses, _ = eng.final_optimize(acc)
         assert np.allclose(traj, poses, rtol=2e-5, atol=2e-5)
         assert not np.allclose(traj, eng.initial_poses(), atol=1e-3)
+    else:
+        assert np.allclose(traj[:, :3], poses[:, 9:], rtol=2e-5, atol=2e-5)
+        # writeVertex prints Quaterniond(R) as qx qy qz qw (src/utils.cpp:248-258)
+        q = traj[:, 3:]
+        x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                      2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                      2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=1)
+        assert np.allclose(R, poses[:, :9], atol=1e-4)
 
 
 @pytest.mark.gpu
