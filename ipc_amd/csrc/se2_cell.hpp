@@ -41,6 +41,8 @@
 //     gfx950's v_permlane32_swap / v_permlane16_swap to reduce four values per register, and
 //     the 6x6 capacitance solve runs on wave 0 only.
 #pragma once
+#include <type_traits>
+
 #include "block_prims.hpp"
 
 namespace ipc {
@@ -320,7 +322,6 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     Pose2 X[M];                                      // committed poses
     Pose2 Xn[M];                                     // trial poses
     double ex[M], ey[M], eth[M];                     // committed odometry errors of edge j (j-1 -> j)
-    double enx[M], eny[M], enth[M];                  // trial errors
     double bx[M], by[M], bth[M];                     // b = -J^T Om e
     double hx[M], hy[M], hth[M];                     // Gauss-Newton step
     bool valid[M];
@@ -344,7 +345,6 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         hx[s] = hy[s] = hth[s] = 0.0;
         bx[s] = by[s] = bth[s] = 0.0;
         ex[s] = ey[s] = eth[s] = 0.0;
-        enx[s] = eny[s] = enth[s] = 0.0;
     }
     __syncthreads();                                 // sh.lc visible
     int lf[NL], lt[NL];
@@ -523,8 +523,11 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #define IPC_ETICK(k)
 #define IPC_ESTART()
 #endif
-    auto evaluate = [&](const Pose2 (&Y)[M], double (&ox)[M], double (&oy)[M], double (&oth)[M], int bsel,
-                        bool changed, bool& anyChanged) -> double {
+    // keep: store the odometry errors (committed state); trials only need chi2 -- an accepted
+    // trial recomputes its errors once (recommit_errors), which is cheaper than carrying a second
+    // error array in registers through every phase.
+    auto evaluate = [&](const Pose2 (&Y)[M], auto keep_c, int bsel, bool changed, bool& anyChanged) -> double {
+        constexpr bool KEEP = decltype(keep_c)::value != 0;
         IPC_ESTART()
         Se2Scratch<W, NL>& S = sh.scr[phase & 1];
         publish_poses(Y, S, bsel);
@@ -539,9 +542,10 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
 #pragma unroll
         for (int s = 0; s < M; ++s) {
             if (!valid[s]) continue;
-            se2_error(An[s], Y[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s),
-                      ox[s], oy[s], oth[s]);
-            part += ldsym(F_OM, s).quad(ox[s], oy[s], oth[s]);
+            double e0, e1, e2;
+            se2_error(An[s], Y[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+            part += ldsym(F_OM, s).quad(e0, e1, e2);
+            if (KEEP) { ex[s] = e0; ey[s] = e1; eth[s] = e2; }
         }
         IPC_ETICK(2)
         if (tid < NL) part += loop_eval(tid, bsel);
@@ -565,7 +569,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
     double currentChi;
     {
         bool dummy;
-        currentChi = evaluate(X, ex, ey, eth, cur, false, dummy);
+        currentChi = evaluate(X, std::integral_constant<int, 1>{}, cur, false, dummy);
         edge = edgeN;
         ++evals;
     }
@@ -1013,7 +1017,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             } else changed = true;
             const int trial = cur ^ 1;
             bool anyChanged;
-            const double newChi = evaluate(Xn, enx, eny, enth, trial, changed, anyChanged);
+            const double newChi = evaluate(Xn, std::integral_constant<int, 0>{}, trial, changed, anyChanged);
             ++evals;
             const double nonLinearGain = currentChi - newChi;
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
@@ -1028,7 +1032,21 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 cur = trial;
                 edge = edgeN;
 #pragma unroll
-                for (int s = 0; s < M; ++s) { X[s] = Xn[s]; ex[s] = enx[s]; ey[s] = eny[s]; eth[s] = enth[s]; }
+                for (int s = 0; s < M; ++s) {
+                    X[s] = Xn[s];
+                    // (hidden from CSE: otherwise the trial pass keeps half of its error arithmetic alive)
+                    asm volatile("" : "+v"(X[s].x), "+v"(X[s].y), "+v"(X[s].th));
+                }
+                {   // errors of the new committed state (same arithmetic as the trial pass, no barrier)
+                    Pose2 An[M];
+                    prev_pose(X, edge, An);
+#pragma unroll
+                    for (int s = 0; s < M; ++s) {
+                        if (!valid[s]) continue;
+                        se2_error(An[s], X[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s),
+                                  ex[s], ey[s], eth[s]);
+                    }
+                }
             }
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
