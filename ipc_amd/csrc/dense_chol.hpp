@@ -58,10 +58,12 @@ __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k
 #pragma unroll
         for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
         x[c] = v / D[c][c];
-    }
-#pragma unroll
-    for (int c = 0; c < kCB; ++c)
+        // Store at once: the LDS reads of the unrolled triangle are ordered memory operations, the
+        // arithmetic is not -- left free it sinks towards one block of stores at the end, every
+        // loaded operand stays live and the kernel spills 600 registers.  A store per column pins
+        // the arithmetic of that column in place.
         if (c < nb) A[(size_t)(k0 + c) * ld + row] = x[c];
+    }
 }
 
 // Trailing update C[i][j] -= sum_p A[i][k0+p] A[j][k0+p] for k1 <= j <= i, i <= n (row n = rhs),

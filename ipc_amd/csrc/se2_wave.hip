@@ -88,6 +88,10 @@ hipError_t launch_se2_wave(int nl, int M, int n, hipStream_t st, const Se2View& 
         IPC_WCASE(1)
         IPC_WCASE(3)
         IPC_WCASE(5)
+        IPC_WCASE(7)
+        IPC_WCASE(9)
+        IPC_WCASE(11)
+        IPC_WCASE(13)
 #endif
         default: return hipErrorInvalidValue;
     }

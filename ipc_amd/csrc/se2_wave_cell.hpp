@@ -85,10 +85,15 @@ __device__ __forceinline__ bool ldl_solve(double (&A)[N][N], double (&b)[N])
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-// The per-slot loops are fully unrolled (the state lives in registers); without a fence the
-// scheduler interleaves all M slots and the temporaries of M slots are live at once (> 1000
-// VGPRs at M = 13).  One scheduling barrier per slot keeps the live set at state + one slot.
+// The per-slot loops are fully unrolled (the state lives in registers).  Memory operations keep
+// their source order, pure arithmetic does not: left alone it sinks towards its final uses, every
+// operand loaded for the M slots stays live and the kernel spills (> 1000 VGPRs at M = 13).  An
+// empty volatile asm that consumes the results of a slot pins that slot's arithmetic in place;
+// the scheduling barrier keeps the next slot's loads behind it.
 #define IPC_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define IPC_PIN1(a) asm volatile("" : "+v"(a) : : "memory")
+#define IPC_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
+#define IPC_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
 
 template <int M, int NL, bool STAGED>
 __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
@@ -291,6 +296,10 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             }
             if (MODE == 2) X[s] = Y;
             prev = Y;
+            if (MODE != 2) IPC_PIN1(part);
+            if (MODE != 1) IPC_PIN3(ex[s], ey[s], eth[s]);
+            IPC_PIN3(prev.x, prev.y, prev.th);
+            IPC_PIN2(prev.c, prev.s);
             IPC_SLOT_FENCE();
         }
         if (MODE == 2) return 0.0;
@@ -354,6 +363,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 bx[s] = v ? tx : 0.0; by[s] = v ? ty : 0.0; bth[s] = v ? tth : 0.0;
                 bbp += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
                 nx = mx; ny = my; nth = mth;
+                IPC_PIN3(bx[s], by[s], bth[s]);
+                IPC_PIN3(nx, ny, nth);
+                IPC_PIN1(bbp);
                 IPC_SLOT_FENCE();
             }
         }
@@ -423,6 +435,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                     for (int k = 0; k < 6; ++k) { v2[3 + k] += m2 * psi[k]; v2[9 + k] += m12 * psi[k]; }
                 }
                 qbx = bx[s]; qby = by[s]; qbth = bth[s];
+                asm volatile("" : "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]), "+v"(v1[4]), "+v"(v1[5]),
+                             "+v"(v1[6]), "+v"(v1[7]), "+v"(v1[8]), "+v"(v1[9]), "+v"(v1[10]) : : "memory");
+                if constexpr (NL == 2)
+                    asm volatile("" : "+v"(v2[0]), "+v"(v2[1]), "+v"(v2[2]), "+v"(v2[3]), "+v"(v2[4]), "+v"(v2[5]),
+                                 "+v"(v2[6]), "+v"(v2[7]), "+v"(v2[8]), "+v"(v2[9]), "+v"(v2[10]), "+v"(v2[11]),
+                                 "+v"(v2[12]), "+v"(v2[13]), "+v"(v2[14]) : : "memory");
                 IPC_SLOT_FENCE();
             }
             wave_sum16_store(v1, &sh.red[0]);
@@ -534,6 +552,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 hy[s] = v ? sn * ux + c * uy : 0.0;
                 run += v ? uth : 0.0;
                 hth[s] = run;                        // in-lane inclusive prefix of rho_theta
+                IPC_PIN3(hx[s], hy[s], hth[s]);
                 IPC_SLOT_FENCE();
             }
             const double offT = wave_inclusive_scan(run) - run;        // h_theta of the lane's predecessor pose
@@ -548,6 +567,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 ry += v ? hy[s] + dx * thPrev : 0.0;
                 hx[s] = rx; hy[s] = ry;
                 thPrev = hth[s];
+                IPC_PIN3(hx[s], hy[s], hth[s]);
                 IPC_SLOT_FENCE();
             }
             const double offX = wave_inclusive_scan(rx) - rx, offY = wave_inclusive_scan(ry) - ry;
