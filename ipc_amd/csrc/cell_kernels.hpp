@@ -41,7 +41,7 @@ hipError_t launch_se3_block(int nl, int variant, int n, hipStream_t st, const Se
                             SolveParams prm, CellOut out);
 
 // ---- wave kernels (SE2): one wave per cell, M consecutive poses per lane; capacity 64*M ----
-static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13};
+static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13, 15};
 constexpr int kNumWaveM = sizeof(kWaveM) / sizeof(kWaveM[0]);
 constexpr int kWaveVariantBase = 100;         // plan variant id of the wave kernel with M poses per lane = base + M
 

@@ -95,7 +95,10 @@ template <int V> struct IntC { static constexpr int value = V; };
 #define IPC_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
 #define IPC_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
 
-template <int M, int NL, bool STAGED>
+// KEEP_E: the odometry errors of the committed state live in registers (3 doubles per pose).  For
+// large M they are recomputed from the poses where needed (three times per iteration, ~20 flops
+// each) to stay inside the register file; a commit is then a pure pose update.
+template <int M, int NL, bool STAGED, bool KEEP_E = (M <= 9)>
 __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
                                WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res)
 {
@@ -126,7 +129,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 
     // ---------------- per-lane state ----------------
     Pose2 X[M];
-    double ex[M], ey[M], eth[M];
+    double ex[KEEP_E ? M : 1], ey[KEEP_E ? M : 1], eth[KEEP_E ? M : 1];
     double bx[M], by[M], bth[M];
     double hx[M], hy[M], hth[M];
     Pose2 gauge;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         X[s].y = P.pose0[(size_t)P.V + ja];
         X[s].th = P.pose0[(size_t)2 * P.V + ja];
         sincos_pi(X[s].th, X[s].s, X[s].c);
-        ex[s] = ey[s] = eth[s] = 0.0;
+        if (KEEP_E) ex[s] = ey[s] = eth[s] = 0.0;
         bx[s] = by[s] = bth[s] = 0.0;
         hx[s] = hy[s] = hth[s] = 0.0;
     }
@@ -246,8 +249,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #pragma unroll
         for (int s = 0; s < M; ++s) {
             asm volatile("" : "+v"(X[s].x), "+v"(X[s].y), "+v"(X[s].c), "+v"(X[s].s));
-            asm volatile("" : "+v"(ex[s]), "+v"(ey[s]), "+v"(eth[s]));
+            if (KEEP_E) asm volatile("" : "+v"(ex[s]), "+v"(ey[s]), "+v"(eth[s]));
         }
+    };
+    // error of edge j (slot s) at the committed poses: from registers, or recomputed
+    auto err_of = [&](int s, const Pose2& a, double& e0, double& e1, double& e2) {
+        if (KEEP_E) { e0 = ex[s]; e1 = ey[s]; e2 = eth[s]; return; }
+        se2_error(a, X[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+        if (!(j0 + s <= L)) { e0 = 0.0; e1 = 0.0; e2 = 0.0; }
     };
     auto sweep = [&](auto mode_c, bool big, double p, double q, int bsel) -> double {
         constexpr int MODE = decltype(mode_c)::value;
@@ -274,13 +283,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             const Pose2 Y = MODE == 0 ? X[s] : (s == M - 1 ? last : stepped(s));
             const bool v = j0 + s <= L;
             if (MODE == 1) changed |= v && ((Y.x != X[s].x) || (Y.y != X[s].y) || (Y.th != X[s].th));
-            double e0, e1, e2;
-            se2_error(prev, Y, ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            if (MODE != 2 || KEEP_E)
+                se2_error(prev, Y, ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
             if (MODE != 2) {
                 const double c2 = ldsym(F_OM, s).quad(e0, e1, e2);
                 part += v ? c2 : 0.0;
             }
-            if (MODE != 1) { ex[s] = v ? e0 : 0.0; ey[s] = v ? e1 : 0.0; eth[s] = v ? e2 : 0.0; }
+            if (MODE != 1 && KEEP_E) { ex[s] = v ? e0 : 0.0; ey[s] = v ? e1 : 0.0; eth[s] = v ? e2 : 0.0; }
             if (MODE != 2) {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
@@ -297,7 +307,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             if (MODE == 2) X[s] = Y;
             prev = Y;
             if (MODE != 2) IPC_PIN1(part);
-            if (MODE != 1) IPC_PIN3(ex[s], ey[s], eth[s]);
+            if (MODE != 1 && KEEP_E) IPC_PIN3(ex[s], ey[s], eth[s]);
+            if (MODE == 2) IPC_PIN3(X[s].x, X[s].y, X[s].th);
             IPC_PIN3(prev.x, prev.y, prev.th);
             IPC_PIN2(prev.c, prev.s);
             IPC_SLOT_FENCE();
@@ -329,8 +340,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                          double& mth) {
             const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
             const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
-            double qx, qy, qth;
-            ldsym(F_OM, s).mul(ex[s], ey[s], eth[s], qx, qy, qth);      // e is zero on idle slots
+            double e0, e1, e2, qx, qy, qth;
+            err_of(s, a, e0, e1, e2);                                   // zero on idle slots
+            ldsym(F_OM, s).mul(e0, e1, e2, qx, qy, qth);
             gx = cP * qx - sP * qy;
             gy = sP * qx + cP * qy;
             gth = qth;
@@ -419,9 +431,11 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 psi[1] = C01 - kx * c1 - ky * psi[2];
                 psi[3] = C11 - ky * c1 - ky * psi[4];
                 psi[5] = sth;
-                const double w0 = c * ex[s] - sn * ey[s] - kx * eth[s];
-                const double w1 = sn * ex[s] + c * ey[s] - ky * eth[s];
-                const double w2 = eth[s];
+                double e0, e1, e2;
+                err_of(s, a, e0, e1, e2);
+                const double w0 = c * e0 - sn * e1 - kx * e2;
+                const double w1 = sn * e0 + c * e1 - ky * e2;
+                const double w2 = e2;
                 const int j = j0 + s;
                 const double m1 = (v && j > llo[0] && j <= lhi[0]) ? 1.0 : 0.0;
                 v1[2] += m1 * w0; v1[3] += m1 * w1; v1[4] += m1 * w2;
@@ -547,7 +561,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
                 double vx, vy, vth;
                 ldsym(F_SG, s).mul(wx, wy, wth, vx, vy, vth);
-                const double ux = -vx - ex[s], uy = -vy - ey[s], uth = -vth - eth[s];
+                double e0, e1, e2;
+                err_of(s, a, e0, e1, e2);
+                const double ux = -vx - e0, uy = -vy - e1, uth = -vth - e2;
                 hx[s] = v ? c * ux - sn * uy : 0.0;
                 hy[s] = v ? sn * ux + c * uy : 0.0;
                 run += v ? uth : 0.0;
@@ -658,12 +674,17 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     double mx = 0.0;
     bool nan = false;
     opaque();
+    {
+        const Pose2 a0 = prev0(X[M - 1]);
 #pragma unroll
-    for (int s = 0; s < M; ++s) {
-        if (j0 + s > L) continue;
-        const double c = ldsym(F_OM, s).quad(ex[s], ey[s], eth[s]);
-        if (c != c) nan = true;
-        else mx = fmax(mx, c);
+        for (int s = 0; s < M; ++s) {
+            double e0, e1, e2;
+            err_of(s, s == 0 ? a0 : X[s - 1], e0, e1, e2);
+            if (j0 + s > L) continue;
+            const double c = ldsym(F_OM, s).quad(e0, e1, e2);
+            if (c != c) nan = true;
+            else mx = fmax(mx, c);
+        }
     }
     mx = wave_max(mx);
     nan = __ballot(nan) != 0ull;
