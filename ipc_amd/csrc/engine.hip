@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // waves per cell, M poses per lane) or "wM" tokens (SE2 wave kernel, one wave per cell, M poses
 // per lane); a cell goes to the listed variant of smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
-static const char* kDefaultPolicy = "w1,w3,w5,2x3,2x4,2x5,2x6,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,w13,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
