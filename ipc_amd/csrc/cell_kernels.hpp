@@ -50,4 +50,11 @@ constexpr int kWaveVariantBase = 100;         // plan variant id of the wave ker
 hipError_t launch_se2_wave(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
                            SolveParams prm, CellOut out, unsigned* counter, int n_cu);
 
+// ---- pair kernels (SE2): two waves per cell, M consecutive poses per lane; capacity 128*M ----
+static const int kPairM[] = {5, 6, 7, 8, 9, 10, 11};
+constexpr int kNumPairM = sizeof(kPairM) / sizeof(kPairM[0]);
+constexpr int kPairVariantBase = 200;
+hipError_t launch_se2_pair(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
+                           SolveParams prm, CellOut out, unsigned* counter, int n_cu);
+
 }  // namespace ipc

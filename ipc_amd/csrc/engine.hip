@@ -327,10 +327,11 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // ------------------------------------------------------------------------------------------
 // Chain-length bins: each bin is served by one (W, M) kernel variant.  The policy string
 // (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens (block kernel, W
-// waves per cell, M poses per lane) or "wM" tokens (SE2 wave kernel, one wave per cell, M poses
-// per lane); a cell goes to the listed variant of smallest capacity 64*W*M that holds it.
+// waves per cell, M poses per lane), "wM" tokens (SE2 wave kernel, one wave per cell, M poses per
+// lane) or "pM" tokens (SE2 pair kernel, two waves per cell); a cell goes to the listed variant of
+// smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
-static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,w13,7x2,8x2,6x3,7x3,8x3,16x2,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,8x3,16x2,16x4,16x8,16x16";
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
@@ -349,6 +350,9 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
         if (dim == 2 && sscanf(tok.c_str(), "w%d", &m) == 1) {          // wave kernel, M poses per lane
             w = 1;
             for (int k = 0; k < kNumWaveM; ++k) if (kWaveM[k] == m) v = kWaveVariantBase + m;
+        } else if (dim == 2 && sscanf(tok.c_str(), "p%d", &m) == 1) {   // pair kernel, two waves per cell
+            w = 2;
+            for (int k = 0; k < kNumPairM; ++k) if (kPairM[k] == m) v = kPairVariantBase + m;
         } else {
             if (sscanf(tok.c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
             for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
@@ -652,7 +656,10 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             const int var = h->plan.variant[b];
             hipError_t e;
             if (h->dim == 2)
-                e = var >= kWaveVariantBase
+                e = var >= kPairVariantBase
+                        ? launch_se2_pair(nl, var - kPairVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                                          h->d_wave_ctr + s, h->n_cu)
+                    : var >= kWaveVariantBase
                         ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
                         : launch_se2_block(nl, var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);

@@ -24,12 +24,22 @@
 namespace ipc {
 
 template <int NL>
-struct WaveScratch {          // per wave, LDS
+struct WaveScratch {          // per cell (one wave, or a pair of waves), LDS
     LoopConst lc[NL];
     LoopState ls[2][NL];
     double lvec[NL][2][3];
-    double red[32];
-    double gam[NL * 9];       // Gamma_l of the capacitance assembly
+    double red[2][32];        // wide reduction, one row per wave of the cell
+    double gam[2][NL * 9];    // Gamma_l of the capacitance assembly (each wave keeps its own copy)
+};
+
+// Mailbox of a wave pair that solves one cell together (W == 2).  The two waves run on different
+// SIMDs of the same workgroup and execute the same sequence of exchanges; an exchange is "write
+// my values, post my sequence number, wait for the partner's, read the partner's values", double
+// buffered on the sequence parity.  LDS operations of one wave complete in order, so the data is
+// visible before the flag.
+struct PairBox {
+    double data[2][2][8];     // [wave of the pair][parity][value]
+    int flag[2];
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -98,16 +108,77 @@ template <int V> struct IntC { static constexpr int value = V; };
 // KEEP_E: the odometry errors of the committed state live in registers (3 doubles per pose).  For
 // large M they are recomputed from the poses where needed (three times per iteration, ~20 flops
 // each) to stay inside the register file; a commit is then a pure pose update.
-template <int M, int NL, bool STAGED, bool KEEP_E = (M <= 9)>
+template <int M, int NL, bool STAGED, int W = 1, bool KEEP_E = (M <= 9)>
 __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
-                               WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res)
+                               WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res,
+                               PairBox* box = nullptr, int seq0 = 0, int* seq_out = nullptr)
 {
+    static_assert(W == 1 || W == 2, "one wave or a pair of waves per cell");
     constexpr int NS = NL * 3;
     const int lane = threadIdx.x & 63;
-    const int j0 = lane * M + 1;                     // pose index of slot 0
+    const int wsub = W == 2 ? ((threadIdx.x >> 6) & 1) : 0;      // wave of the pair
+    const int gl = wsub * 64 + lane;                 // lane index within the cell
+    const int j0 = gl * M + 1;                       // pose index of slot 0
+
+    // ---- pair exchange (W == 2): up to 8 doubles each way; also the pair's barrier ----
+    int seq = seq0;
+    auto xchg = [&](const double (&mine)[8], int n, double (&theirs)[8]) {
+        if constexpr (W == 2) {
+            ++seq;
+            double* my = box->data[wsub][seq & 1];
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < n) my[k] = mine[k];
+            }
+            wave_sync();
+            if (lane == 0) __hip_atomic_store(&box->flag[wsub], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&box->flag[wsub ^ 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
+                __builtin_amdgcn_s_sleep(1);
+            wave_sync();
+            const double* th = box->data[wsub ^ 1][seq & 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) theirs[k] = k < n ? th[k] : 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) theirs[k] = 0.0;
+        }
+    };
+    auto pair_barrier = [&]() {
+        if constexpr (W == 2) { double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8]; xchg(a, 0, b); }
+    };
+    // sum over the cell of a per-lane value: wave 0's total + wave 1's, in that order on both
+    auto cell_sum = [&](double v) -> double {
+        const double t = wave_sum(v);
+        if constexpr (W == 2) {
+            double a[8] = {t, 0, 0, 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 1, b);
+            return wsub == 0 ? t + b[0] : b[0] + t;
+        }
+        return t;
+    };
+    auto cell_sum2 = [&](double v0, double v1, double& s0, double& s1) {
+        const double t0 = wave_sum(v0), t1 = wave_sum(v1);
+        if constexpr (W == 2) {
+            double a[8] = {t0, t1, 0, 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 2, b);
+            s0 = wsub == 0 ? t0 + b[0] : b[0] + t0;
+            s1 = wsub == 0 ? t1 + b[1] : b[1] + t1;
+        } else { s0 = t0; s1 = t1; }
+    };
+    // exclusive prefix over the cell's lanes of a per-lane total
+    auto cell_excl = [&](double run) -> double {
+        const double inc = wave_inclusive_scan(run);
+        double off = inc - run;
+        if constexpr (W == 2) {
+            double a[8] = {read_lane(inc, 63), 0, 0, 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 1, b);
+            if (wsub == 1) off += b[0];
+        }
+        return off;
+    };
 
     // ---------------- loop constants -> LDS ----------------
-    if (lane < NL) {
+    if (lane < NL && wsub == 0) {
         const int l = lane, c = cand[l];
         LoopConst& q = sh.lc[l];
         q.f = P.cand_from[c] - lo_abs;
@@ -150,6 +221,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         hx[s] = hy[s] = hth[s] = 0.0;
     }
     wave_sync();                                     // sh.lc visible
+    pair_barrier();
     int lf[NL], lt[NL], of[NL], sf[NL], ot[NL], st_[NL], llo[NL], lhi[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -159,7 +231,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         of[l] = lf[l] > 0 ? (lf[l] - 1) / M : -1; sf[l] = lf[l] > 0 ? (lf[l] - 1) % M : -1;
         ot[l] = lt[l] > 0 ? (lt[l] - 1) / M : -1; st_[l] = lt[l] > 0 ? (lt[l] - 1) % M : -1;
     }
-    if (lane == 0) {                                 // gauge end points never change
+    if (gl == 0) {                                   // gauge end points never change
 #pragma unroll
         for (int l = 0; l < NL; ++l)
 #pragma unroll
@@ -177,7 +249,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     // The constants are loop-invariant, so the compiler would hoist every load out of the dog-leg
     // loop and pin 17 doubles per slot in registers; opaque() makes the index look modified, which
     // keeps the loads where they are used.
-    int eloc = lane * M < L ? lane * M : 0;
+    int eloc = gl * M < L ? gl * M : 0;
     auto opaque = [&]() { asm volatile("" : "+v"(eloc)); };
     auto ldc = [&](int field, int s) -> double {
         if (STAGED && field < (int)F_SG) return cst[field * wstride + (lo_abs - wlo + eloc) + s];
@@ -189,12 +261,39 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         m.a11 = ldc(field0 + 3, s); m.a12 = ldc(field0 + 4, s); m.a22 = ldc(field0 + 5, s);
         return m;
     };
-    // pose j-1 of slot 0: slot M-1 of the lane below (lane 0: the gauge)
+    // pose j-1 of slot 0: slot M-1 of the lane below (lane 0 of the cell: the gauge; lane 0 of the
+    // pair's second wave: lane 63 of the first, through the mailbox)
     auto prev0 = [&](const Pose2& last) -> Pose2 {
+        Pose2 cr = gauge;
+        if constexpr (W == 2) {
+            double a[8] = {read_lane(last.x, 63), read_lane(last.y, 63), read_lane(last.th, 63), read_lane(last.c, 63),
+                           read_lane(last.s, 63), 0, 0, 0}, b[8];
+            xchg(a, 5, b);
+            if (wsub == 1) { cr.x = b[0]; cr.y = b[1]; cr.th = b[2]; cr.c = b[3]; cr.s = b[4]; }
+        }
         Pose2 p;
-        p.x = lane_prev(last.x, gauge.x); p.y = lane_prev(last.y, gauge.y); p.th = lane_prev(last.th, gauge.th);
-        p.c = lane_prev(last.c, gauge.c); p.s = lane_prev(last.s, gauge.s);
+        p.x = lane_prev(last.x, cr.x); p.y = lane_prev(last.y, cr.y); p.th = lane_prev(last.th, cr.th);
+        p.c = lane_prev(last.c, cr.c); p.s = lane_prev(last.s, cr.s);
         return p;
+    };
+    // 3-vector of the lane below / above across the pair (0 at the ends of the cell)
+    auto prev3 = [&](double vx, double vy, double vth, double& ox, double& oy, double& oth) {
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if constexpr (W == 2) {
+            double a[8] = {read_lane(vx, 63), read_lane(vy, 63), read_lane(vth, 63), 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 3, b);
+            if (wsub == 1) { c0 = b[0]; c1 = b[1]; c2 = b[2]; }
+        }
+        ox = lane_prev(vx, c0); oy = lane_prev(vy, c1); oth = lane_prev(vth, c2);
+    };
+    auto next3 = [&](double vx, double vy, double vth, double& ox, double& oy, double& oth) {
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if constexpr (W == 2) {
+            double a[8] = {read_lane(vx, 0), read_lane(vy, 0), read_lane(vth, 0), 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 3, b);
+            if (wsub == 0) { c0 = b[0]; c1 = b[1]; c2 = b[2]; }
+        }
+        ox = lane_next(vx, c0); oy = lane_next(vy, c1); oth = lane_next(vth, c2);
     };
 
     auto loop_eval = [&](int l, int bsel) -> double {
@@ -275,7 +374,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             return Y;
         };
         const Pose2 last = MODE == 0 ? X[M - 1] : stepped(M - 1);
-        Pose2 prev = prev0(last);
+        Pose2 prev = last;
+        if (MODE != 2 || KEEP_E) prev = prev0(last);  // (a commit without stored errors needs no neighbour)
         double part = 0.0;
         bool changed = false;
 #pragma unroll
@@ -294,11 +394,11 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             if (MODE != 2) {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
-                    if (sf[l] == s && lane == of[l]) {
+                    if (sf[l] == s && gl == of[l]) {
                         double* w = sh.ls[bsel][l].pf;
                         w[0] = Y.x; w[1] = Y.y; w[2] = Y.th; w[3] = Y.c; w[4] = Y.s;
                     }
-                    if (st_[l] == s && lane == ot[l]) {
+                    if (st_[l] == s && gl == ot[l]) {
                         double* w = sh.ls[bsel][l].pt;
                         w[0] = Y.x; w[1] = Y.y; w[2] = Y.th; w[3] = Y.c; w[4] = Y.s;
                     }
@@ -315,9 +415,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         }
         if (MODE == 2) return 0.0;
         wave_sync();
-        if (lane < NL) part += loop_eval(lane, bsel);
-        if (MODE == 1) sweepChanged = __ballot(changed) != 0ull;
-        return wave_sum(part);
+        pair_barrier();                               // end points of both waves are in place
+        if (gl < NL) part += loop_eval(gl, bsel);
+        double tot, chg;
+        cell_sum2(part, (MODE == 1 && changed) ? 1.0 : 0.0, tot, chg);
+        if (MODE == 1) sweepChanged = chg != 0.0;
+        return tot;
     };
 
     // ---------------- initial errors (consensus_utils.cpp:11) ----------------
@@ -333,9 +436,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         // ---- phase A: forces g, hand-back m -> b ----
         opaque();
         launder();
-        if (lane < NL) loop_force(lane);
+        if (gl < NL) loop_force(gl);
         wave_sync();
-        const Pose2 a0 = prev0(X[M - 1]);
+        const Pose2 a0 = prev0(X[M - 1]);             // (also orders the loop forces before their readers)
         auto force = [&](int s, const Pose2& a, double& gx, double& gy, double& gth, double& mx, double& my,
                          double& mth) {
             const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
@@ -354,7 +457,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         {
             double g0x, g0y, g0th, m0x, m0y, m0th;
             force(0, a0, g0x, g0y, g0th, m0x, m0y, m0th);
-            double nx = lane_next(m0x, 0.0), ny = lane_next(m0y, 0.0), nth = lane_next(m0th, 0.0);
+            double nx, ny, nth;
+            next3(m0x, m0y, m0th, nx, ny, nth);
 #pragma unroll
             for (int s = M - 1; s >= 0; --s) {
                 double gx, gy, gth, mx, my, mth;
@@ -365,8 +469,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const LoopState& st = sh.ls[cur][l];
-                    if (st_[l] == s && lane == ot[l]) { tx -= st.g[0]; ty -= st.g[1]; tth -= st.g[2]; }
-                    if (sf[l] == s && lane == of[l]) {
+                    if (st_[l] == s && gl == ot[l]) { tx -= st.g[0]; ty -= st.g[1]; tth -= st.g[2]; }
+                    if (sf[l] == s && gl == of[l]) {
                         const double dx = st.pt[0] - st.pf[0], dy = st.pt[1] - st.pf[1];
                         tx += st.g[0]; ty += st.g[1];
                         tth += st.g[2] + (-dy * st.g[0] + dx * st.g[1]);
@@ -390,14 +494,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             // b at the loop end points (the gauge end point carries zero)
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                if (lane == 0) {
+                if (gl == 0) {
                     if (lf[l] == 0) { sh.lvec[l][0][0] = 0.0; sh.lvec[l][0][1] = 0.0; sh.lvec[l][0][2] = 0.0; }
                     if (lt[l] == 0) { sh.lvec[l][1][0] = 0.0; sh.lvec[l][1][1] = 0.0; sh.lvec[l][1][2] = 0.0; }
                 }
 #pragma unroll
                 for (int s = 0; s < M; ++s) {
-                    if (sf[l] == s && lane == of[l]) { sh.lvec[l][0][0] = bx[s]; sh.lvec[l][0][1] = by[s]; sh.lvec[l][0][2] = bth[s]; }
-                    if (st_[l] == s && lane == ot[l]) { sh.lvec[l][1][0] = bx[s]; sh.lvec[l][1][1] = by[s]; sh.lvec[l][1][2] = bth[s]; }
+                    if (sf[l] == s && gl == of[l]) { sh.lvec[l][0][0] = bx[s]; sh.lvec[l][0][1] = by[s]; sh.lvec[l][0][2] = bth[s]; }
+                    if (st_[l] == s && gl == ot[l]) { sh.lvec[l][1][0] = bx[s]; sh.lvec[l][1][1] = by[s]; sh.lvec[l][1][2] = bth[s]; }
                 }
             }
             // group 1: b^T b, b^T H b, W_1 (3), M_11 (6); group 2: W_2 (3), M_22 (6), M_12 (6)
@@ -405,7 +509,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #pragma unroll
             for (int k = 0; k < 16; ++k) { v1[k] = 0.0; v2[k] = 0.0; }
             v1[0] = bbp;
-            double qbx = lane_prev(bx[M - 1], 0.0), qby = lane_prev(by[M - 1], 0.0), qbth = lane_prev(bth[M - 1], 0.0);
+            double qbx, qby, qbth;
+            prev3(bx[M - 1], by[M - 1], bth[M - 1], qbx, qby, qbth);
 #pragma unroll
             for (int s = 0; s < M; ++s) {
                 const Pose2& a = s == 0 ? a0 : X[s - 1];
@@ -457,14 +562,16 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                                  "+v"(v2[12]), "+v"(v2[13]), "+v"(v2[14]) : : "memory");
                 IPC_SLOT_FENCE();
             }
-            wave_sum16_store(v1, &sh.red[0]);
-            if constexpr (NL == 2) wave_sum16_store(v2, &sh.red[16]);
+            wave_sum16_store(v1, &sh.red[wsub][0]);
+            if constexpr (NL == 2) wave_sum16_store(v2, &sh.red[wsub][16]);
             wave_sync();
+            pair_barrier();                           // both waves' partial sums and end-point vectors are in place
             // ---- capacitance solve, lane-parallel (a uniform 6x6 solve in registers would pin ~150
             // VGPRs while the whole chain state is live):
             //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> gam[.]
             //   lane r*(NS+1)+c  : S[r][c] (c < NS) / rhs d[r] (c == NS), then Gauss-Jordan in place
-            const double* wt = sh.red;
+            auto wtv = [&](int k) -> double { return W == 2 ? sh.red[0][k] + sh.red[1][k] : sh.red[0][k]; };
+            double* gamw = sh.gam[wsub];
             if (lane < NL * 9) {
                 const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
                 const LoopConst& q = sh.lc[l];
@@ -475,7 +582,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 if (i == 0) g = a == 0 ? Aq : (a == 1 ? Bq : Aq * Kx + Bq * Ky);
                 else if (i == 1) g = a == 0 ? -Bq : (a == 1 ? Aq : -Bq * Kx + Aq * Ky);
                 else g = a == 2 ? 1.0 : 0.0;
-                sh.gam[lane] = q.sigma * g;
+                gamw[lane] = q.sigma * g;
             }
             wave_sync();
             constexpr int RS = NS + 1;                    // row stride of the augmented system
@@ -483,22 +590,22 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             const int r = lane / RS, c = lane % RS;
             if (lane < NS * RS) {
                 const int l1 = r / 3, i = r % 3;
-                const double g10 = sh.gam[l1 * 9 + i * 3], g11 = sh.gam[l1 * 9 + i * 3 + 1], g12 = sh.gam[l1 * 9 + i * 3 + 2];
+                const double g10 = gamw[l1 * 9 + i * 3], g11 = gamw[l1 * 9 + i * 3 + 1], g12 = gamw[l1 * 9 + i * 3 + 2];
                 if (c < NS) {
                     const int l2 = c / 3, k = c % 3;
                     const int mb = l1 == l2 ? (l1 == 0 ? 5 : 19) : 25;
-                    const double m00 = wt[mb], m01 = wt[mb + 1], m02 = wt[mb + 2], m11 = wt[mb + 3], m12 = wt[mb + 4], m22 = wt[mb + 5];
+                    const double m00 = wtv(mb), m01 = wtv(mb + 1), m02 = wtv(mb + 2), m11 = wtv(mb + 3), m12 = wtv(mb + 4), m22 = wtv(mb + 5);
                     const double t0 = g10 * m00 + g11 * m01 + g12 * m02;
                     const double t1 = g10 * m01 + g11 * m11 + g12 * m12;
                     const double t2 = g10 * m02 + g11 * m12 + g12 * m22;
-                    val = t0 * sh.gam[l2 * 9 + k * 3] + t1 * sh.gam[l2 * 9 + k * 3 + 1] + t2 * sh.gam[l2 * 9 + k * 3 + 2];
+                    val = t0 * gamw[l2 * 9 + k * 3] + t1 * gamw[l2 * 9 + k * 3 + 1] + t2 * gamw[l2 * 9 + k * 3 + 2];
                     if (l1 == l2) {
                         const int lo_ = i < k ? i : k, hi_ = i < k ? k : i;
                         val += sh.lc[l1].sg[lo_ * 3 - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)];
                     }
                 } else {
                     const int wb = l1 == 0 ? 2 : 16;
-                    val = sh.ls[cur][l1].e[i] - (g10 * wt[wb] + g11 * wt[wb + 1] + g12 * wt[wb + 2]);
+                    val = sh.ls[cur][l1].e[i] - (g10 * wtv(wb) + g11 * wtv(wb + 1) + g12 * wtv(wb + 2));
                 }
             }
             bool okS = true;
@@ -519,15 +626,15 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
                     const double mu_r = __shfl(val, (3 * l + rr) * RS + NS, 64);
-                    nv += sh.gam[l * 9 + rr * 3 + cc] * mu_r;
+                    nv += gamw[l * 9 + rr * 3 + cc] * mu_r;
                 }
 #pragma unroll
                 for (int l2 = 0; l2 < NL; ++l2)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) nu[l2][k] = read_lane(nv, 3 * l2 + k);
             }
-            bb = wt[0];
-            bHb = wt[1];
+            bb = wtv(0);
+            bHb = wtv(1);
             {
                 const double lq = lane < NL ? loop_quad(lane) : 0.0;
 #pragma unroll
@@ -571,7 +678,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 IPC_PIN3(hx[s], hy[s], hth[s]);
                 IPC_SLOT_FENCE();
             }
-            const double offT = wave_inclusive_scan(run) - run;        // h_theta of the lane's predecessor pose
+            const double offT = cell_excl(run);                        // h_theta of the lane's predecessor pose
             double rx = 0.0, ry = 0.0, thPrev = offT;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
@@ -586,7 +693,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 IPC_PIN3(hx[s], hy[s], hth[s]);
                 IPC_SLOT_FENCE();
             }
-            const double offX = wave_inclusive_scan(rx) - rx, offY = wave_inclusive_scan(ry) - ry;
+            const double offX = cell_excl(rx), offY = cell_excl(ry);
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
@@ -597,8 +704,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 p0 += hx[s] * hx[s] + hy[s] * hy[s] + hth[s] * hth[s];
                 p1 += bx[s] * hx[s] + by[s] * hy[s] + bth[s] * hth[s];
             }
-            hgnNorm = sqrt(wave_sum(p0));
-            bh = wave_sum(p1);
+            double hh;
+            cell_sum2(p0, p1, hh, bh);
+            hgnNorm = sqrt(hh);
             hHh = bh;
         }
         // ---- trial loop ----
@@ -620,7 +728,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                     p0 += sx * ax + sy * ay + sth * ath;
                     p1 += ax * ax + ay * ay + ath * ath;
                 }
-                const double c = wave_sum(p0), bma = wave_sum(p1), hsdSq = alpha * alpha * bb;
+                double c, bma;
+                cell_sum2(p0, p1, c, bma);
+                const double hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
                 else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
             }
@@ -688,6 +798,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     }
     mx = wave_max(mx);
     nan = __ballot(nan) != 0ull;
+    if constexpr (W == 2) {
+        double a[8] = {mx, nan ? 1.0 : 0.0, 0, 0, 0, 0, 0, 0}, b[8];
+        xchg(a, 2, b);
+        mx = fmax(mx, b[0]);
+        nan = nan || b[1] != 0.0;
+    }
     wave_sync();
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -702,6 +818,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     res.tries = tries_total;
     res.flags = flags;
     res.evals = evals;
+    if (seq_out) *seq_out = seq;
 }
 
 }  // namespace ipc
