@@ -99,7 +99,8 @@ template <int V> struct IntC { static constexpr int value = V; };
 // their source order, pure arithmetic does not: left alone it sinks towards its final uses, every
 // operand loaded for the M slots stays live and the kernel spills (> 1000 VGPRs at M = 13).  An
 // empty volatile asm that consumes the results of a slot pins that slot's arithmetic in place;
-// the scheduling barrier keeps the next slot's loads behind it.
+// the scheduling barrier keeps the next slot's loads behind it (measured: without it the kernels
+// use a few registers less but C2 runs 6 % slower).
 #define IPC_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define IPC_PIN1(a) asm volatile("" : "+v"(a) : : "memory")
 #define IPC_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b) : : "memory")
