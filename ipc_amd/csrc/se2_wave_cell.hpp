@@ -262,6 +262,22 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         m.a11 = ldc(field0 + 3, s); m.a12 = ldc(field0 + 4, s); m.a22 = ldc(field0 + 5, s);
         return m;
     };
+    // Constants of one slot, fetched ONE SLOT AHEAD of their use: the per-slot fences keep a slot's
+    // loads inside that slot, so without the look-ahead every slot starts by waiting for its own LDS
+    // (or L2) reads.  WANT bits: 1 measurement translation + angle, 2 measurement rotation,
+    // 4 information, 8 covariance.
+    struct SlotConst { double tzx, tzy, thz, cz, sz; Sym3 om, sg; };
+    auto ld_slot = [&](int s, SlotConst& c, auto want_c) {
+        constexpr int WANT = decltype(want_c)::value;
+        if (WANT & 1) { c.tzx = ldc(F_TZX, s); c.tzy = ldc(F_TZY, s); c.thz = ldc(F_THZ, s); }
+        if (WANT & 2) { c.cz = ldc(F_CZ, s); c.sz = ldc(F_SZ, s); }
+        if (WANT & 4) c.om = ldsym(F_OM, s);
+        if (WANT & 8) c.sg = ldsym(F_SG, s);
+    };
+    constexpr int kErrWant = KEEP_E ? 0 : 3;         // what err_of needs when the errors are recomputed
+    // the look-ahead costs one SlotConst of registers: only where the register file has room
+    constexpr bool PF = M <= 7;
+
     // pose j-1 of slot 0: slot M-1 of the lane below (lane 0 of the cell: the gauge; lane 0 of the
     // pair's second wave: lane 63 of the first, through the mailbox)
     auto prev0 = [&](const Pose2& last) -> Pose2 {
@@ -353,9 +369,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         }
     };
     // error of edge j (slot s) at the committed poses: from registers, or recomputed
-    auto err_of = [&](int s, const Pose2& a, double& e0, double& e1, double& e2) {
+    auto err_of = [&](int s, const Pose2& a, const SlotConst& K, double& e0, double& e1, double& e2) {
         if (KEEP_E) { e0 = ex[s]; e1 = ey[s]; e2 = eth[s]; return; }
-        se2_error(a, X[s], ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+        se2_error(a, X[s], K.tzx, K.tzy, K.cz, K.sz, K.thz, e0, e1, e2);
         if (!(j0 + s <= L)) { e0 = 0.0; e1 = 0.0; e2 = 0.0; }
     };
     auto sweep = [&](auto mode_c, bool big, double p, double q, int bsel) -> double {
@@ -379,16 +395,21 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         if (MODE != 2 || KEEP_E) prev = prev0(last);  // (a commit without stored errors needs no neighbour)
         double part = 0.0;
         bool changed = false;
+        constexpr int kWant = (MODE != 2 || KEEP_E) ? (MODE != 2 ? 7 : 3) : 0;
+        SlotConst Kn;
+        if (PF) ld_slot(0, Kn, IntC<kWant>{});
 #pragma unroll
         for (int s = 0; s < M; ++s) {
+            SlotConst K;
+            if (PF) { K = Kn; if (s + 1 < M) ld_slot(s + 1, Kn, IntC<kWant>{}); }
+            else ld_slot(s, K, IntC<kWant>{});
             const Pose2 Y = MODE == 0 ? X[s] : (s == M - 1 ? last : stepped(s));
             const bool v = j0 + s <= L;
             if (MODE == 1) changed |= v && ((Y.x != X[s].x) || (Y.y != X[s].y) || (Y.th != X[s].th));
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-            if (MODE != 2 || KEEP_E)
-                se2_error(prev, Y, ldc(F_TZX, s), ldc(F_TZY, s), ldc(F_CZ, s), ldc(F_SZ, s), ldc(F_THZ, s), e0, e1, e2);
+            if (MODE != 2 || KEEP_E) se2_error(prev, Y, K.tzx, K.tzy, K.cz, K.sz, K.thz, e0, e1, e2);
             if (MODE != 2) {
-                const double c2 = ldsym(F_OM, s).quad(e0, e1, e2);
+                const double c2 = K.om.quad(e0, e1, e2);
                 part += v ? c2 : 0.0;
             }
             if (MODE != 1 && KEEP_E) { ex[s] = v ? e0 : 0.0; ey[s] = v ? e1 : 0.0; eth[s] = v ? e2 : 0.0; }
@@ -440,13 +461,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         if (gl < NL) loop_force(gl);
         wave_sync();
         const Pose2 a0 = prev0(X[M - 1]);             // (also orders the loop forces before their readers)
-        auto force = [&](int s, const Pose2& a, double& gx, double& gy, double& gth, double& mx, double& my,
-                         double& mth) {
-            const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+        constexpr int kWantA = 2 | 4 | kErrWant;
+        auto force = [&](int s, const Pose2& a, const SlotConst& K, double& gx, double& gy, double& gth, double& mx,
+                         double& my, double& mth) {
+            const double cz = K.cz, sz = K.sz;
             const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
             double e0, e1, e2, qx, qy, qth;
-            err_of(s, a, e0, e1, e2);                                   // zero on idle slots
-            ldsym(F_OM, s).mul(e0, e1, e2, qx, qy, qth);
+            err_of(s, a, K, e0, e1, e2);                                // zero on idle slots
+            K.om.mul(e0, e1, e2, qx, qy, qth);
             gx = cP * qx - sP * qy;
             gy = sP * qx + cP * qy;
             gth = qth;
@@ -457,14 +479,25 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         double bbp = 0.0;
         {
             double g0x, g0y, g0th, m0x, m0y, m0th;
-            force(0, a0, g0x, g0y, g0th, m0x, m0y, m0th);
+            SlotConst Kn;
+            {
+                SlotConst K0;
+                ld_slot(0, K0, IntC<kWantA>{});
+                if (PF && M > 1) ld_slot(M - 1, Kn, IntC<kWantA>{});
+                force(0, a0, K0, g0x, g0y, g0th, m0x, m0y, m0th);
+            }
             double nx, ny, nth;
             next3(m0x, m0y, m0th, nx, ny, nth);
 #pragma unroll
             for (int s = M - 1; s >= 0; --s) {
                 double gx, gy, gth, mx, my, mth;
                 if (s == 0) { gx = g0x; gy = g0y; gth = g0th; mx = m0x; my = m0y; mth = m0th; }
-                else force(s, X[s - 1], gx, gy, gth, mx, my, mth);
+                else {
+                    SlotConst K;
+                    if (PF) { K = Kn; if (s - 1 > 0) ld_slot(s - 1, Kn, IntC<kWantA>{}); }
+                    else ld_slot(s, K, IntC<kWantA>{});
+                    force(s, X[s - 1], K, gx, gy, gth, mx, my, mth);
+                }
                 const bool v = j0 + s <= L;
                 double tx = nx - gx, ty = ny - gy, tth = nth - gth;
 #pragma unroll
@@ -512,16 +545,22 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             v1[0] = bbp;
             double qbx, qby, qbth;
             prev3(bx[M - 1], by[M - 1], bth[M - 1], qbx, qby, qbth);
+            constexpr int kWantB = 2 | 4 | 8 | kErrWant;
+            SlotConst Kn;
+            if (PF) ld_slot(0, Kn, IntC<kWantB>{});
 #pragma unroll
             for (int s = 0; s < M; ++s) {
+                SlotConst K;
+                if (PF) { K = Kn; if (s + 1 < M) ld_slot(s + 1, Kn, IntC<kWantB>{}); }
+                else ld_slot(s, K, IntC<kWantB>{});
                 const Pose2& a = s == 0 ? a0 : X[s - 1];
                 const bool v = j0 + s <= L;
-                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                const double cz = K.cz, sz = K.sz;
                 double wx, wy, wth;
                 se2_apply_J(a, X[s], cz, sz, qbx, qby, qbth, bx[s], by[s], bth[s], wx, wy, wth);
-                const double hq = ldsym(F_OM, s).quad(wx, wy, wth);
+                const double hq = K.om.quad(wx, wy, wth);
                 v1[1] += v ? hq : 0.0;
-                const Sym3 sg = ldsym(F_SG, s);
+                const Sym3 sg = K.sg;
                 const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
                 const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;
                 const double cc = c * c, ss = sn * sn, cs = c * sn;
@@ -538,7 +577,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 psi[3] = C11 - ky * c1 - ky * psi[4];
                 psi[5] = sth;
                 double e0, e1, e2;
-                err_of(s, a, e0, e1, e2);
+                err_of(s, a, K, e0, e1, e2);
                 const double w0 = c * e0 - sn * e1 - kx * e2;
                 const double w1 = sn * e0 + c * e1 - ky * e2;
                 const double w2 = e2;
@@ -652,8 +691,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         {
             // rho into (hx, hy, hth); theta prefix in-lane
             double run = 0.0;
+            constexpr int kWantC = 2 | 8 | kErrWant;
+            SlotConst Kn;
+            if (PF) ld_slot(0, Kn, IntC<kWantC>{});
 #pragma unroll
             for (int s = 0; s < M; ++s) {
+                SlotConst K;
+                if (PF) { K = Kn; if (s + 1 < M) ld_slot(s + 1, Kn, IntC<kWantC>{}); }
+                else ld_slot(s, K, IntC<kWantC>{});
                 const Pose2& a = s == 0 ? a0 : X[s - 1];
                 const int j = j0 + s;
                 const bool v = j <= L;
@@ -663,14 +708,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                     const double m2 = (v && j > llo[1] && j <= lhi[1]) ? 1.0 : 0.0;
                     n0 += m2 * nu[1][0]; n1 += m2 * nu[1][1]; n2 += m2 * nu[1][2];
                 }
-                const double cz = ldc(F_CZ, s), sz = ldc(F_SZ, s);
+                const double cz = K.cz, sz = K.sz;
                 const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
                 const double kx = -(X[s].y - gauge.y), ky = X[s].x - gauge.x;
                 const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
                 double vx, vy, vth;
-                ldsym(F_SG, s).mul(wx, wy, wth, vx, vy, vth);
+                K.sg.mul(wx, wy, wth, vx, vy, vth);
                 double e0, e1, e2;
-                err_of(s, a, e0, e1, e2);
+                err_of(s, a, K, e0, e1, e2);
                 const double ux = -vx - e0, uy = -vy - e1, uth = -vth - e2;
                 hx[s] = v ? c * ux - sn * uy : 0.0;
                 hy[s] = v ? sn * ux + c * uy : 0.0;
@@ -789,10 +834,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         const Pose2 a0 = prev0(X[M - 1]);
 #pragma unroll
         for (int s = 0; s < M; ++s) {
+            SlotConst K;
+            ld_slot(s, K, IntC<(4 | kErrWant)>{});
             double e0, e1, e2;
-            err_of(s, s == 0 ? a0 : X[s - 1], e0, e1, e2);
+            err_of(s, s == 0 ? a0 : X[s - 1], K, e0, e1, e2);
             if (j0 + s > L) continue;
-            const double c = ldsym(F_OM, s).quad(e0, e1, e2);
+            const double c = K.om.quad(e0, e1, e2);
             if (c != c) nan = true;
             else mx = fmax(mx, c);
         }
