@@ -188,7 +188,7 @@ def main():
         import csv
         f = w = 0.0
         for r in csv.DictReader(open(pmc_csv)):
-            if "_cells_kernel" in r["kernel"] or "_wave_kernel" in r["kernel"]:
+            if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_pair_kernel")):
                 if r["counter"] == "FETCH_SIZE":
                     f += float(r["sum_value"])
                 elif r["counter"] == "WRITE_SIZE":
@@ -201,7 +201,7 @@ def main():
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
                                 "L2-resident" % args.workload,
                 "kernel": "se%d_cells_kernel<W,M,NL>%s (%d launches per step, one per chain-length bin and loop count)" % (
-                    g.dim, " + se2_wave_kernel<M,NL,STAGED>" if g.dim == 2 else "", launches),
+                    g.dim, " + se2_wave_kernel<M,NL,STAGED> + se2_pair_kernel<M,NL,STAGED>" if g.dim == 2 else "", launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
