@@ -178,6 +178,16 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         return off;
     };
 
+    auto cell_excl2 = [&](double r0, double r1, double& o0, double& o1) {
+        const double i0 = wave_inclusive_scan(r0), i1 = wave_inclusive_scan(r1);
+        o0 = i0 - r0; o1 = i1 - r1;
+        if constexpr (W == 2) {
+            double a[8] = {read_lane(i0, 63), read_lane(i1, 63), 0, 0, 0, 0, 0, 0}, b[8];
+            xchg(a, 2, b);
+            if (wsub == 1) { o0 += b[0]; o1 += b[1]; }
+        }
+    };
+
     // ---------------- loop constants -> LDS ----------------
     if (lane < NL && wsub == 0) {
         const int l = lane, c = cand[l];
@@ -437,12 +447,24 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         }
         if (MODE == 2) return 0.0;
         wave_sync();
-        pair_barrier();                               // end points of both waves are in place
-        if (gl < NL) part += loop_eval(gl, bsel);
-        double tot, chg;
-        cell_sum2(part, (MODE == 1 && changed) ? 1.0 : 0.0, tot, chg);
-        if (MODE == 1) sweepChanged = chg != 0.0;
-        return tot;
+        if constexpr (W == 2) {
+            // one exchange: the partial sums of both waves; it also tells each wave that the
+            // partner's loop end points are in place, so the loops are evaluated after it (by both
+            // waves, same values; the first wave's lanes store the loop state)
+            double tot, chg;
+            cell_sum2(part, (MODE == 1 && changed) ? 1.0 : 0.0, tot, chg);
+            const double lc = lane < NL ? loop_eval(lane, bsel) : 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) tot += read_lane(lc, l);
+            if (MODE == 1) sweepChanged = chg != 0.0;
+            return tot;
+        } else {
+            if (lane < NL) part += loop_eval(lane, bsel);
+            double tot, chg;
+            cell_sum2(part, (MODE == 1 && changed) ? 1.0 : 0.0, tot, chg);
+            if (MODE == 1) sweepChanged = chg != 0.0;
+            return tot;
+        }
     };
 
     // ---------------- initial errors (consensus_utils.cpp:11) ----------------
@@ -739,7 +761,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 IPC_PIN3(hx[s], hy[s], hth[s]);
                 IPC_SLOT_FENCE();
             }
-            const double offX = cell_excl(rx), offY = cell_excl(ry);
+            double offX, offY;
+            cell_excl2(rx, ry, offX, offY);
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int s = 0; s < M; ++s) {
