@@ -32,7 +32,8 @@ static const Variant kVariants[] = {
     {3, 4}, {3, 5}, {3, 6}, {4, 3}, {4, 5},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4} };
+static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4},
+                                      {4, 2}, {4, 4}, {8, 2}, {8, 4}, {4, 8}, {8, 5} };
 constexpr int kNumVariants3 = sizeof(kVariants3) / sizeof(kVariants3[0]);
 
 hipError_t launch_se2_block(int nl, int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,

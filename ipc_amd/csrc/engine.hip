@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
 static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,8x3,16x2,16x4,16x8,16x16";
-static const char* kDefaultPolicy3 = "1x1,2x1,4x1,8x1,16x1,16x2,16x4";
+static const char* kDefaultPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
     const char* env = getenv(dim == 2 ? "IPC_SE2_POLICY" : "IPC_SE3_POLICY");

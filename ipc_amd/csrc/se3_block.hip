@@ -46,6 +46,12 @@ static hipError_t launch_se3(int variant, int n, hipStream_t st, const Se3View& 
         IPC_CASE3(4, 16, 1)
         IPC_CASE3(5, 16, 2)
         IPC_CASE3(6, 16, 4)
+        IPC_CASE3(7, 4, 2)
+        IPC_CASE3(8, 4, 4)
+        IPC_CASE3(9, 8, 2)
+        IPC_CASE3(10, 8, 4)
+        IPC_CASE3(11, 4, 8)
+        IPC_CASE3(12, 8, 5)
         default: return hipErrorInvalidValue;
     }
 #undef IPC_CASE3

@@ -16,6 +16,8 @@
 //   G_{l,j} = sigma_l D(E_l) T(X_j^-1 X_to(l)) D(E_j)^-1  for lo_l < j <= hi_l,
 //   T(X) = [[R^T, -2 R^T [t]x], [0, R^T]].
 #pragma once
+#include <type_traits>
+
 #include "block_prims.hpp"
 
 namespace ipc {
@@ -330,7 +332,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
 
     // ---------------- per-lane state ----------------
     Pose3 X[M], Xn[M];
-    double e[M][6], en[M][6], b[M][6], h[M][6];
+    double e[M][6], b[M][6], h[M][6];
     bool valid[M];
     unsigned eoff[M];
     Pose3 gauge;
@@ -350,7 +352,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
         for (int k = 0; k < 3; ++k) X[s].t[k] = P.pose0[(size_t)(9 + k) * P.V + ja];
         Xn[s] = X[s];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { e[s][k] = en[s][k] = b[s][k] = h[s][k] = 0.0; }
+        for (int k = 0; k < 6; ++k) { e[s][k] = b[s][k] = h[s][k] = 0.0; }
     }
     __syncthreads();
     int lf[NL], lt[NL];
@@ -497,7 +499,10 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
     };
 
     Pose3 edge = gauge, edgeN = gauge;
-    auto evaluate = [&](const Pose3 (&Y)[M], double (&oe)[M][6], int bsel, bool changed, bool& anyChanged) -> double {
+    // keep: store the odometry errors (committed state); trial passes only need chi2 -- an accepted
+    // trial recomputes its errors once, which is cheaper than a second error array in registers
+    auto evaluate = [&](const Pose3 (&Y)[M], auto keep_c, int bsel, bool changed, bool& anyChanged) -> double {
+        constexpr bool KEEP = decltype(keep_c)::value != 0;
         Se3Scratch<W, NL>& S = sh.scr[phase & 1];
         publish_poses(Y, S, bsel);
         __syncthreads();
@@ -513,8 +518,10 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             ld_rz(s, Rz, tz);
             Edge3 E;
             se3_edge(An[s], Y[s], Rz, tz, E);
+            if (KEEP) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) oe[s][k] = E.e[k];
+                for (int k = 0; k < 6; ++k) e[s][k] = E.e[k];
+            }
             ld_sym(G_OM, s, om);
             part += sym6_quad(om, E.e);
         }
@@ -535,7 +542,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
     double currentChi;
     {
         bool dummy;
-        currentChi = evaluate(X, e, cur, false, dummy);
+        currentChi = evaluate(X, std::integral_constant<int, 1>{}, cur, false, dummy);
         edge = edgeN;
         ++evals;
     }
@@ -1075,7 +1082,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             }
             const int trial = cur ^ 1;
             bool anyChanged;
-            const double newChi = evaluate(Xn, en, trial, changed, anyChanged);
+            const double newChi = evaluate(Xn, std::integral_constant<int, 0>{}, trial, changed, anyChanged);
             ++evals;
             const double nonLinearGain = currentChi - newChi;
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
@@ -1091,7 +1098,21 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                 for (int s = 0; s < M; ++s) {
                     X[s] = Xn[s];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) e[s][k] = en[s][k];
+                    for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(X[s].t[k]));   // (hidden from CSE with the trial pass)
+                }
+                {   // errors of the new committed state (same arithmetic as the trial pass, no barrier)
+                    Pose3 An[M];
+                    prev_pose(X, edge, An);
+#pragma unroll
+                    for (int s = 0; s < M; ++s) {
+                        if (!valid[s]) continue;
+                        double Rz[9], tz[3];
+                        ld_rz(s, Rz, tz);
+                        Edge3 E;
+                        se3_edge(An[s], X[s], Rz, tz, E);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) e[s][k] = E.e[k];
+                    }
                 }
             }
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
