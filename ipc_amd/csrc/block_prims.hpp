@@ -67,28 +67,16 @@ __device__ __forceinline__ double wave_max(double v)
 // After pair32(a,b): lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l].
 __device__ __forceinline__ double pair32(double a, double b)
 {
-#ifdef DBG_SWAP_NOP
-    asm volatile("s_nop 7" ::: "memory");
-#endif
     auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
     auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-#ifdef DBG_SWAP_NOP
-    asm volatile("s_nop 7" ::: "memory");
-#endif
     return mk_double(hi[0], lo[0]) + mk_double(hi[1], lo[1]);
 }
 // After pair16(a,b): row0 = a.row0+a.row1, row1 = b.row0+b.row1, row2 = a.row2+a.row3,
 // row3 = b.row2+b.row3 (rows of 16 lanes, element-wise).
 __device__ __forceinline__ double pair16(double a, double b)
 {
-#ifdef DBG_SWAP_NOP
-    asm volatile("s_nop 7" ::: "memory");
-#endif
     auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
     auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-#ifdef DBG_SWAP_NOP
-    asm volatile("s_nop 7" ::: "memory");
-#endif
     return mk_double(hi[0], lo[0]) + mk_double(hi[1], lo[1]);
 }
 // Wave sums of 16 per-lane values: dst[k] = sum over the 64 lanes of v[k] (written by one lane
@@ -96,11 +84,6 @@ __device__ __forceinline__ double pair16(double a, double b)
 __device__ __forceinline__ void wave_sum16_store(const double (&v)[16], double* dst)
 {
     const int lane = threadIdx.x & 63;
-#ifdef DBG_PLAIN_SUM16
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const double t = wave_sum(v[k]); if (lane == 0) dst[k] = t; }
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         // value index after the two packing levels: row r of q holds v[i + 4 r]
@@ -119,11 +102,6 @@ template <int K>
 __device__ __forceinline__ void gather_totals(const double* red, int nw, double (&tot)[K])
 {
     const int lane = threadIdx.x & 63;
-#ifdef DBG_PLAIN_GATHER
-#pragma unroll
-    for (int q = 0; q < K; ++q) { double a = 0.0; for (int w = 0; w < nw; ++w) a += red[q * 16 + w]; tot[q] = a; }
-    return;
-#endif
     const int k = lane >> 4, w = lane & 15;
     double v = (k < K && w < nw) ? red[k * 16 + w] : 0.0;
     v = row_inclusive_scan(v);

@@ -583,7 +583,7 @@ static Se2View make_view(const ipc_engine* h)
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     P.dbg = nullptr;
-#if defined(DBG_SIDE) || defined(IPC_PHASE_TIMING)
+#if defined(IPC_PHASE_TIMING)
     static double* dbgbuf = nullptr;
     if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
     P.dbg = dbgbuf;
@@ -783,7 +783,7 @@ extern "C" int ipc_solver_time_ms(ipc_engine_t* h, double* ms, int* launches)
     return IPC_OK;
 }
 
-#if defined(DBG_SIDE) || defined(IPC_PHASE_TIMING)
+#if defined(IPC_PHASE_TIMING)
 extern "C" int ipc_dbg_read(ipc_engine_t* h, double* out, int n)
 {
     Se2View P = make_view(h);
