@@ -109,7 +109,13 @@ template <int V> struct IntC { static constexpr int value = V; };
 // KEEP_E: the odometry errors of the committed state live in registers (3 doubles per pose).  For
 // large M they are recomputed from the poses where needed (three times per iteration, ~20 flops
 // each) to stay inside the register file; a commit is then a pure pose update.
-template <int M, int NL, bool STAGED, int W = 1, bool KEEP_E = (M <= 9)>
+#ifndef IPC_KEEPE_MAX
+#define IPC_KEEPE_MAX 8
+#endif
+#ifndef IPC_PF_MAX
+#define IPC_PF_MAX 7
+#endif
+template <int M, int NL, bool STAGED, int W = 1, bool KEEP_E = (M <= IPC_KEEPE_MAX)>
 __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
                                WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res,
                                PairBox* box = nullptr, int seq0 = 0, int* seq_out = nullptr)
@@ -286,7 +292,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     };
     constexpr int kErrWant = KEEP_E ? 0 : 3;         // what err_of needs when the errors are recomputed
     // the look-ahead costs one SlotConst of registers: only where the register file has room
-    constexpr bool PF = M <= 7;
+    constexpr bool PF = M <= IPC_PF_MAX;
 
     // pose j-1 of slot 0: slot M-1 of the lane below (lane 0 of the cell: the gauge; lane 0 of the
     // pair's second wave: lane 63 of the first, through the mailbox)
