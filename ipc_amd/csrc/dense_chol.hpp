@@ -25,18 +25,33 @@ __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k
         D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + c) * ld + k0 + r] : (r == c ? 1.0 : 0.0);
     }
     __syncthreads();
+    // Factor the diagonal block in registers: lane r holds row r; column c of the factor reaches the
+    // other rows through v_readlane (constant lane), so the 32 elimination steps are straight-line
+    // code without LDS round trips.  Rows >= nb are identity rows.
     bool ok = true;
-    for (int c = 0; c < nb; ++c) {
-        const double piv = D[c][c];
-        if (!(piv > 0)) ok = false;
-        const double d = sqrt(piv), inv = 1.0 / d;
-        __syncthreads();
-        if (lane == c) D[c][c] = d;
-        else if (lane > c && lane < nb) D[lane][c] *= inv;
-        __syncthreads();
+    {
         const int r = lane & 31;
-        for (int cc = c + 1 + (lane >> 5); cc < nb; cc += 2)
-            if (r >= cc && r < nb) D[r][cc] -= D[r][c] * D[cc][c];
+        double row[kCB];
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) row[c] = D[r][c];
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) {
+            const double piv = read_lane(row[c], c);
+            if (!(piv > 0)) ok = false;
+            const double d = sqrt(piv), inv = 1.0 / d;
+            const double lrc = r == c ? d : (r > c ? row[c] * inv : 0.0);
+            row[c] = lrc;
+#pragma unroll
+            for (int cc = c + 1; cc < kCB; ++cc) {
+                const double lcc = read_lane(lrc, cc);       // L[cc][c]
+                if (r >= cc) row[cc] = fma(-lrc, lcc, row[cc]);
+            }
+        }
+        __syncthreads();
+        if (lane < kCB) {
+#pragma unroll
+            for (int c = 0; c < kCB; ++c) D[r][c] = row[c];
+        }
         __syncthreads();
     }
     if (blockIdx.x == 0) {
