@@ -1,5 +1,5 @@
 // Launch interface of the cell-solver kernels.  The kernels are heavily templated, so they live
-// in their own translation units (se2_block.hip, se2_wave.hip, se3_block.hip) that are compiled
+// in their own translation units (se2_block.hip, se2_wave.hip, se2_pair.hip, se3_block.hip) that are compiled
 // in parallel and linked into libipc_amd.so; engine.hip only sees these prototypes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,7 +42,7 @@ hipError_t launch_se3_block(int nl, int variant, int n, hipStream_t st, const Se
                             SolveParams prm, CellOut out);
 
 // ---- wave kernels (SE2): one wave per cell, M consecutive poses per lane; capacity 64*M ----
-static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13, 15};
+static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13};
 constexpr int kNumWaveM = sizeof(kWaveM) / sizeof(kWaveM[0]);
 constexpr int kWaveVariantBase = 100;         // plan variant id of the wave kernel with M poses per lane = base + M
 
@@ -52,7 +52,7 @@ hipError_t launch_se2_wave(int nl, int M, int n, hipStream_t st, const Se2View& 
                            SolveParams prm, CellOut out, unsigned* counter, int n_cu);
 
 // ---- pair kernels (SE2): two waves per cell, M consecutive poses per lane; capacity 128*M ----
-static const int kPairM[] = {5, 6, 7, 8, 9, 10, 11};
+static const int kPairM[] = {5, 7, 9, 11};
 constexpr int kNumPairM = sizeof(kPairM) / sizeof(kPairM[0]);
 constexpr int kPairVariantBase = 200;
 hipError_t launch_se2_pair(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
