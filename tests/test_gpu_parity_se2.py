@@ -285,3 +285,31 @@ def test_matrix_mode_vs_faithful_incremental_mode(oracle):
     assert agree >= 0.9, agree
     # the matrix mode is the stricter one on true loops (the diagonal uses the fast threshold)
     assert np.all(acc <= inc) or agree >= 0.95
+
+
+def test_kernel_families_agree_with_each_other(oracle, monkeypatch):
+    """The same cells through the wave kernels, the pair kernels and the block kernels: identical
+    decisions, chi2 equal to round-off (they share the mathematics, not the summation order)."""
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth._se2_graph(640, 40, seed=21, laps=4.0, name="fam"), 60, seed=8)
+    results = {}
+    for name, pol in (("wave", "w1,w3,w5,w7,w9,w11,w13"), ("pair", "p5,p7,p9,p11"), ("block", "2x1,4x1,8x1,8x2,16x2"),
+                      ("default", None)):
+        if pol is None:
+            monkeypatch.delenv("IPC_SE2_POLICY", raising=False)
+        else:
+            monkeypatch.setenv("IPC_SE2_POLICY", pol)
+        eng, cfg = _engine(g)
+        bits, acc = eng.run()
+        c = eng.cell_info()
+        order = np.lexsort((c["j"], c["i"]))
+        results[name] = (bits.copy(), acc.copy(), c[order])
+        eng.close()
+    ref_bits, ref_acc, ref_cells = results["block"]
+    for name in ("wave", "pair", "default"):
+        bits, acc, cells = results[name]
+        assert np.array_equal(bits, ref_bits), name
+        assert np.array_equal(acc, ref_acc), name
+        assert np.array_equal(cells["i"], ref_cells["i"]) and np.array_equal(cells["j"], ref_cells["j"])
+        a, b = cells["max_chi2"], ref_cells["max_chi2"]
+        assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-12)), name
