@@ -248,6 +248,14 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         of[l] = lf[l] > 0 ? (lf[l] - 1) / M : -1; sf[l] = lf[l] > 0 ? (lf[l] - 1) % M : -1;
         ot[l] = lt[l] > 0 ? (lt[l] - 1) / M : -1; st_[l] = lt[l] > 0 ? (lt[l] - 1) % M : -1;
     }
+    // Slots of THIS wave that hold a loop end point (wave-uniform bit mask): the per-slot loops test
+    // one bit instead of running the four owner checks in every slot.
+    unsigned ownSlots = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (of[l] >= 0 && (of[l] >> 6) == wsub) ownSlots |= 1u << sf[l];
+        if (ot[l] >= 0 && (ot[l] >> 6) == wsub) ownSlots |= 1u << st_[l];
+    }
     if (gl == 0) {                                   // gauge end points never change
 #pragma unroll
         for (int l = 0; l < NL; ++l)
@@ -429,7 +437,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 part += v ? c2 : 0.0;
             }
             if (MODE != 1 && KEEP_E) { ex[s] = v ? e0 : 0.0; ey[s] = v ? e1 : 0.0; eth[s] = v ? e2 : 0.0; }
-            if (MODE != 2) {
+            if (MODE != 2 && ((ownSlots >> s) & 1u)) {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     if (sf[l] == s && gl == of[l]) {
@@ -528,6 +536,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 }
                 const bool v = j0 + s <= L;
                 double tx = nx - gx, ty = ny - gy, tth = nth - gth;
+                if ((ownSlots >> s) & 1u) {
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const LoopState& st = sh.ls[cur][l];
@@ -537,6 +546,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                         tx += st.g[0]; ty += st.g[1];
                         tth += st.g[2] + (-dy * st.g[0] + dx * st.g[1]);
                     }
+                }
                 }
                 bx[s] = v ? tx : 0.0; by[s] = v ? ty : 0.0; bth[s] = v ? tth : 0.0;
                 bbp += bx[s] * bx[s] + by[s] * by[s] + bth[s] * bth[s];
@@ -562,6 +572,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 }
 #pragma unroll
                 for (int s = 0; s < M; ++s) {
+                    if (!((ownSlots >> s) & 1u)) continue;
                     if (sf[l] == s && gl == of[l]) { sh.lvec[l][0][0] = bx[s]; sh.lvec[l][0][1] = by[s]; sh.lvec[l][0][2] = bth[s]; }
                     if (st_[l] == s && gl == ot[l]) { sh.lvec[l][1][0] = bx[s]; sh.lvec[l][1][1] = by[s]; sh.lvec[l][1][2] = bth[s]; }
                 }
