@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_wave_kernel(Se2Vie
         // residual-pass constants of the whole window, once per workgroup (rows padded with zeros)
         for (int f = 0; f < (int)F_SG; ++f)
             for (int i = threadIdx.x; i < wstride; i += 64 * kWavesPerGroup)
-                cst[f * wstride + i] = i < wlen ? P.chain[(size_t)f * P.estride + wlo + i] : 0.0;
+                cst[i * (int)F_SG + f] = i < wlen ? P.chain[(size_t)f * P.estride + wlo + i] : 0.0;
     }
     __syncthreads();
     for (;;) {

@@ -277,7 +277,10 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     int eloc = gl * M < L ? gl * M : 0;
     auto opaque = [&]() { asm volatile("" : "+v"(eloc)); };
     auto ldc = [&](int field, int s) -> double {
-        if (STAGED && field < (int)F_SG) return cst[field * wstride + (lo_abs - wlo + eloc) + s];
+        // staged window: one record of F_SG doubles per edge, so a slot's constants sit at
+        // compile-time offsets from ONE per-lane address (no address arithmetic, paired reads);
+        // with M odd the lane stride of M * 88 bytes is bank-conflict free
+        if (STAGED && field < (int)F_SG) return cst[((lo_abs - wlo + eloc) + s) * (int)F_SG + field];
         return P.chain[(size_t)field * P.estride + (lo_abs + eloc) + s];
     };
     auto ldsym = [&](int field0, int s) -> Sym3 {
