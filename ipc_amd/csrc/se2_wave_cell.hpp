@@ -401,7 +401,10 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         se2_error(a, X[s], K.tzx, K.tzy, K.cz, K.sz, K.thz, e0, e1, e2);
         if (!(j0 + s <= L)) { e0 = 0.0; e1 = 0.0; e2 = 0.0; }
     };
-    auto sweep = [&](auto mode_c, bool big, double p, double q, int bsel) -> double {
+    // gn (wave-uniform): the step is exactly h (Gauss-Newton trial, p = 0, q = 1): X + (0 b + 1 h) and
+    // X + h are the same bits, so the b operands and two operations per component are skipped.
+    // wantChanged: only a steepest-descent trial needs to know whether any pose moved.
+    auto sweep = [&](auto mode_c, bool big, double p, double q, int bsel, bool gn = false, bool wantChanged = true) -> double {
         constexpr int MODE = decltype(mode_c)::value;
         opaque();
         launder();
@@ -410,9 +413,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         asm volatile("" : "+v"(p), "+v"(q));
         auto stepped = [&](int s) -> Pose2 {
             Pose2 Y;
-            Y.x = X[s].x + fma(p, bx[s], q * hx[s]);
-            Y.y = X[s].y + fma(p, by[s], q * hy[s]);
-            Y.th = wrap_pi(X[s].th + fma(p, bth[s], q * hth[s]));
+            double dx, dy, dth;
+            if (gn) { dx = hx[s]; dy = hy[s]; dth = hth[s]; }
+            else { dx = fma(p, bx[s], q * hx[s]); dy = fma(p, by[s], q * hy[s]); dth = fma(p, bth[s], q * hth[s]); }
+            Y.x = X[s].x + dx;
+            Y.y = X[s].y + dy;
+            Y.th = wrap_pi(X[s].th + dth);
             if (big) sincos_pi(Y.th, Y.s, Y.c);
             else rotate_small(X[s].c, X[s].s, Y.th - X[s].th, Y.c, Y.s);
             return Y;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             else ld_slot(s, K, IntC<kWant>{});
             const Pose2 Y = MODE == 0 ? X[s] : (s == M - 1 ? last : stepped(s));
             const bool v = j0 + s <= L;
-            if (MODE == 1) changed |= v && ((Y.x != X[s].x) || (Y.y != X[s].y) || (Y.th != X[s].th));
+            if (MODE == 1 && wantChanged) changed |= v && ((Y.x != X[s].x) || (Y.y != X[s].y) || (Y.th != X[s].th));
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
             if (MODE != 2 || KEEP_E) se2_error(prev, Y, K.tzx, K.tzy, K.cz, K.sz, K.thz, e0, e1, e2);
             if (MODE != 2) {
@@ -835,12 +841,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             asm volatile("" : "+v"(pc2), "+v"(qc2));
 #pragma unroll
             for (int s = 0; s < M; ++s) {
-                const double thn = wrap_pi(X[s].th + fma(pc2, bth[s], qc2 * hth[s]));
+                const double thn = wrap_pi(X[s].th + (stepType == 0 ? hth[s] : fma(pc2, bth[s], qc2 * hth[s])));
                 big |= fabs(thn - X[s].th) >= 0.015625;
             }
             const bool anyBig = __ballot(big) != 0ull;
             const int trial = cur ^ 1;
-            const double newChi = sweep(IntC<1>{}, anyBig, pcoef, qcoef, trial);
+            const double newChi = sweep(IntC<1>{}, anyBig, pcoef, qcoef, trial, stepType == 0, stepType == 1);
             const bool anyChanged = stepType == 1 ? sweepChanged : true;
             ++evals;
             const double nonLinearGain = currentChi - newChi;
@@ -852,7 +858,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
-                sweep(IntC<2>{}, anyBig, pcoef, qcoef, trial);
+                sweep(IntC<2>{}, anyBig, pcoef, qcoef, trial, stepType == 0, false);
             }
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
