@@ -113,7 +113,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 #define IPC_KEEPE_MAX 8
 #endif
 #ifndef IPC_PF_MAX
-#define IPC_PF_MAX 7
+#define IPC_PF_MAX 9
 #endif
 template <int M, int NL, bool STAGED, int W = 1, bool KEEP_E = (M <= IPC_KEEPE_MAX)>
 __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int L, const int (&cand)[2], int iterations,
