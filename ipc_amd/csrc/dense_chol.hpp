@@ -18,6 +18,7 @@ constexpr int kCB = 32;      // block-column width
 __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k0, int* info)
 {
     __shared__ double D[kCB][kCB + 1];
+    __shared__ double Dinv[kCB];
     const int lane = threadIdx.x;
     const int nb = min(kCB, n - k0);
     for (int idx = lane; idx < kCB * kCB; idx += 64) {
@@ -52,6 +53,12 @@ __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k
 #pragma unroll
             for (int c = 0; c < kCB; ++c) D[r][c] = row[c];
         }
+        // reciprocal of the diagonal, one division per lane instead of one per row and column
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) {
+            const double dcc = read_lane(row[c], c);
+            if (lane == c) Dinv[c] = 1.0 / dcc;
+        }
         __syncthreads();
     }
     if (blockIdx.x == 0) {
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k
         double v = x[c];
 #pragma unroll
         for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
-        x[c] = v / D[c][c];
+        x[c] = v * Dinv[c];
         // Store at once: the LDS reads of the unrolled triangle are ordered memory operations, the
         // arithmetic is not -- left free it sinks towards one block of stores at the end, every
         // loaded operand stays live and the kernel spills 600 registers.  A store per column pins
@@ -146,8 +153,9 @@ __global__ __launch_bounds__(1024) void chol_backsolve(const double* A, int n, i
         __syncthreads();
         if (wave == 0) {
             double v = lane < nb ? A[(size_t)(k0 + lane) * ld + n] - t[lane] : 0.0;
+            const double dinv = lane < nb ? 1.0 / D[lane][lane] : 0.0;      // one division per lane, not per step
             for (int r = nb - 1; r >= 0; --r) {
-                const double xr = __shfl(v, r, 64) / D[r][r];
+                const double xr = __shfl(v, r, 64) * __shfl(dinv, r, 64);
                 if (lane == r) v = xr;
                 else if (lane < r) v -= D[r][lane] * xr;
             }
