@@ -195,7 +195,7 @@ def main():
                     w += float(r["sum_value"])
         traffic = (2.0 * f + w) * 1024.0
     achieved_tflops = flops / (sms * 1e-3) / 1e12
-    roofline = {"bound": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
+    roofline = {"bound": "mfma", "compute_unit": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
                 "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
@@ -205,8 +205,9 @@ def main():
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
-                "note": "FP64 vector ALU is the binding roof (MI355X: FP64 VALU = dense FP64 MFMA = 78.6 TFLOP/s); "
-                        "the HBM roof is far away, see roofline_hbm"}
+                "note": "compute-bound: priced against the dense FP64 MFMA peak, which on MI355X equals the FP64 "
+                        "vector-ALU peak (78.6 TFLOP/s); the work has no MFMA-shaped products, its instructions "
+                        "issue on the FP64 VALU; the HBM roof is far away, see roofline_hbm"}
     hbm_gbs = alg_bytes / (sms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(hbm_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
