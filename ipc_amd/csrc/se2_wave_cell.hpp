@@ -1,22 +1,28 @@
-// SE(2) cell solver, one WAVE per cell (the variant for chains up to ~64 * 13 poses).
+// SE(2) cell solver, one WAVE (W = 1, chains up to 64 M poses) or a PAIR of waves (W = 2, up to
+// 128 M poses) per cell.
 //
 // The block kernel (se2_cell.hpp) spreads one chain over W waves and pays a workgroup barrier
-// plus an LDS round trip for every reduction / scan / neighbour hand-off; its phases are
-// dominated by those fixed costs, and with one cell resident per CU the other SIMDs idle while
-// wave 0 solves the capacitance system.  Here a cell lives in ONE wave:
+// plus an LDS round trip for every reduction / scan / neighbour hand-off, with one cell resident
+// per CU.  Here:
 //   * lane l owns the M CONSECUTIVE poses l*M+1 .. l*M+M (lane-major), so the chain neighbour
 //     of a slot is the previous slot of the same lane (a register); only slot 0 takes one DPP
 //     shift from the lane below.  Prefix sums are an in-lane serial pass + ONE wave scan,
-//     reductions are in-lane accumulation + ONE wave reduction.  No barrier anywhere.
+//     reductions are in-lane accumulation + ONE wave reduction.  No workgroup barrier anywhere.
 //   * the four waves of a workgroup (one per SIMD, up to 512 registers each) work on four
-//     DIFFERENT cells and fetch the next one from a global counter when done, so a CU always
-//     has four dog-legs in flight and nothing waits for the slowest wave of a cell.
+//     different cells (W = 1) or two (W = 2) and fetch the next one from a global counter when
+//     done, so a CU always has independent dog-legs in flight.
+//   * W = 2: the two waves of a cell exchange the boundary pose / force / step vectors, partial
+//     sums and scan carries through a sequence-numbered, double-buffered LDS mailbox (PairBox).
 //   * the chain constants of the residual pass (5 measurement + 6 information values per edge)
-//     are staged ONCE per workgroup for the whole window of the launch and shared by every cell
-//     it solves (all cells of a launch use the same chain); M is odd so the stride-M ds_read_b64
-//     pattern is bank-conflict free.
+//     are staged ONCE per workgroup for the whole window of the launch, one record per edge, and
+//     shared by every cell it solves; M is odd so the lane stride of M records is bank-conflict
+//     free, and a slot's constants sit at compile-time offsets from one per-lane address.
 //   * trial poses / trial errors are not stored: a trial is one sweep that steps, evaluates and
-//     sums chi2 on the fly; an accepted trial is re-swept once to commit poses and errors.
+//     sums chi2 on the fly; an accepted trial is re-swept once to commit.  For M > 8 the committed
+//     errors are not stored either (recomputed where used).
+//   * with one wave per SIMD every instruction costs issue time: the per-slot code is pinned in
+//     place (IPC_PIN*), loop end points are found by one bit test per slot, constants are fetched
+//     one slot ahead where registers allow.
 // Mathematics, dog-leg control flow and shortcuts are those of se2_cell.hpp.
 #pragma once
 #include "se2_cell.hpp"
