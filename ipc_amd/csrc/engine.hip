@@ -104,6 +104,14 @@ __global__ void k_se2_prep(int n, const double* meas, const double* info, double
     }
 }
 
+// field-major records -> record-major copy (rows beyond n stay zero)
+__global__ void k_se2_records(int n, const double* rec, int stride, double* out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int f = 0; f < (int)F_NFIELDS; ++f) out[(size_t)k * F_NFIELDS + f] = rec[(size_t)f * stride + k];
+}
+
 // propagateGuess (reference src/consensus_utils.cpp:99-116): v0 at origin, v[i] = v[i-1] * z[i-1]
 // (SE2::operator*: t += R t2, theta = normalize(theta + theta2)).  Sequential by nature and run
 // once per engine, so a single lane walks the chain.
@@ -378,6 +386,7 @@ struct ipc_engine {
     hipStream_t own_stream = nullptr;
     // chain
     double* d_chain = nullptr; int estride = 0;
+    double* d_chain_rec = nullptr;                     // SE2: record-major copy [E + 64][F_NFIELDS]
     double* d_pose0 = nullptr;
     // candidates
     double* d_cand = nullptr; int cstride = 0;
@@ -453,6 +462,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
                            params->s_factor, h->d_chain, h->estride);
         hipLaunchKernelGGL(k_se2_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
                            h->d_pose0);
+        HIPCHK(hipMalloc(&h->d_chain_rec, sizeof(double) * (size_t)F_NFIELDS * (E + 64)));
+        HIPCHK(hipMemsetAsync(h->d_chain_rec, 0, sizeof(double) * (size_t)F_NFIELDS * (E + 64), h->own_stream));
+        hipLaunchKernelGGL(k_se2_records, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, h->d_chain, h->estride,
+                           h->d_chain_rec);
     } else {
         hipLaunchKernelGGL(k_se3_prep, dim3((E + 63) / 64), dim3(64), 0, h->own_stream, E, d_m, d_i,
                            params->s_factor, h->d_chain, h->estride);
@@ -481,7 +494,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
     free_candidates(h);
-    hipFree(h->d_chain); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
+    hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
@@ -581,6 +594,7 @@ static Se2View make_view(const ipc_engine* h)
 {
     Se2View P;
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
+    P.chain_rec = h->d_chain_rec;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     P.dbg = nullptr;
 #if defined(IPC_PHASE_TIMING)

@@ -55,6 +55,7 @@ enum Se2Field { F_TZX = 0, F_TZY, F_CZ, F_SZ, F_THZ, F_OM = 5, F_SG = 11, F_NFIE
 struct Se2View {
     const double* chain;      // [F_NFIELDS][estride], index = edge k (joins pose k -> k+1)
     int estride;
+    const double* chain_rec;  // the same values record-major: [edge][F_NFIELDS] (+ zero padding)
     const double* pose0;      // [3][V] open-loop poses x, y, theta
     int V;
     const double* cand;       // [F_NFIELDS][cstride] per loop candidate

@@ -6,7 +6,10 @@
 using namespace ipc;
 
 constexpr int kWavesPerGroup = 4;
-constexpr int kLdsBudget = 160 * 1024;
+#ifndef IPC_LDS_BUDGET
+#define IPC_LDS_BUDGET (160 * 1024)
+#endif
+constexpr int kLdsBudget = IPC_LDS_BUDGET;
 
 // Pair kernel: the four waves of a workgroup form two pairs, each pair solves one cell together
 // (wave 0 of the pair owns poses 1 .. 64 M, wave 1 the next 64 M); the pairs are independent and

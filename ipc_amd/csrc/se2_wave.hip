@@ -50,7 +50,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_wave_kernel(Se2Vie
     }
 }
 
-constexpr int kLdsBudget = 160 * 1024;
+#ifndef IPC_LDS_BUDGET
+#define IPC_LDS_BUDGET (160 * 1024)
+#endif
+constexpr int kLdsBudget = IPC_LDS_BUDGET;
 
 template <int M, int NL>
 static hipError_t launch_one(int n, hipStream_t st, const Se2View& P, const int2* cells, SolveParams prm, CellOut out,

@@ -287,7 +287,9 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         // compile-time offsets from ONE per-lane address (no address arithmetic, paired reads);
         // with M odd the lane stride of M * 88 bytes is bank-conflict free
         if (STAGED && field < (int)F_SG) return cst[((lo_abs - wlo + eloc) + s) * (int)F_SG + field];
-        return P.chain[(size_t)field * P.estride + (lo_abs + eloc) + s];
+        // HBM / L2: record-major copy of the chain, so these loads too are compile-time offsets
+        // from one per-lane address
+        return P.chain_rec[((size_t)(lo_abs + eloc) + s) * (int)F_NFIELDS + field];
     };
     auto ldsym = [&](int field0, int s) -> Sym3 {
         Sym3 m;
