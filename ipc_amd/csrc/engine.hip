@@ -105,11 +105,11 @@ __global__ void k_se2_prep(int n, const double* meas, const double* info, double
 }
 
 // field-major records -> record-major copy (rows beyond n stay zero)
-__global__ void k_se2_records(int n, const double* rec, int stride, double* out)
+__global__ void k_records(int n, int nf, const double* rec, int stride, double* out)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    for (int f = 0; f < (int)F_NFIELDS; ++f) out[(size_t)k * F_NFIELDS + f] = rec[(size_t)f * stride + k];
+    for (int f = 0; f < nf; ++f) out[(size_t)k * nf + f] = rec[(size_t)f * stride + k];
 }
 
 // propagateGuess (reference src/consensus_utils.cpp:99-116): v0 at origin, v[i] = v[i-1] * z[i-1]
@@ -386,7 +386,7 @@ struct ipc_engine {
     hipStream_t own_stream = nullptr;
     // chain
     double* d_chain = nullptr; int estride = 0;
-    double* d_chain_rec = nullptr;                     // SE2: record-major copy [E + 64][F_NFIELDS]
+    double* d_chain_rec = nullptr;                     // record-major copy [E + 64][F_NFIELDS | G_NFIELDS]
     double* d_pose0 = nullptr;
     // candidates
     double* d_cand = nullptr; int cstride = 0;
@@ -464,13 +464,17 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
                            h->d_pose0);
         HIPCHK(hipMalloc(&h->d_chain_rec, sizeof(double) * (size_t)F_NFIELDS * (E + 64)));
         HIPCHK(hipMemsetAsync(h->d_chain_rec, 0, sizeof(double) * (size_t)F_NFIELDS * (E + 64), h->own_stream));
-        hipLaunchKernelGGL(k_se2_records, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, h->d_chain, h->estride,
-                           h->d_chain_rec);
+        hipLaunchKernelGGL(k_records, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, (int)F_NFIELDS, h->d_chain,
+                           h->estride, h->d_chain_rec);
     } else {
         hipLaunchKernelGGL(k_se3_prep, dim3((E + 63) / 64), dim3(64), 0, h->own_stream, E, d_m, d_i,
                            params->s_factor, h->d_chain, h->estride);
         hipLaunchKernelGGL(k_se3_propagate, dim3(1), dim3(64), 0, h->own_stream, n_vertices, h->d_chain, h->estride,
                            h->d_pose0);
+        HIPCHK(hipMalloc(&h->d_chain_rec, sizeof(double) * (size_t)G_NFIELDS * (E + 64)));
+        HIPCHK(hipMemsetAsync(h->d_chain_rec, 0, sizeof(double) * (size_t)G_NFIELDS * (E + 64), h->own_stream));
+        hipLaunchKernelGGL(k_records, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, (int)G_NFIELDS, h->d_chain,
+                           h->estride, h->d_chain_rec);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->own_stream));
@@ -609,6 +613,7 @@ static Se3View make_view3(const ipc_engine* h)
 {
     Se3View P;
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
+    P.chain_rec = h->d_chain_rec;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     return P;
 }

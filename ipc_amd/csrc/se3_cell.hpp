@@ -29,6 +29,7 @@ enum Se3Field { G_RZ = 0, G_TZ = 9, G_OM = 12, G_SG = 33, G_NFIELDS = 54 };
 struct Se3View {
     const double* chain;      // [G_NFIELDS][estride]
     int estride;
+    const double* chain_rec;  // the same values record-major: [edge][G_NFIELDS]
     const double* pose0;      // [12][V] open-loop poses: R row-major (9), t (3)
     int V;
     const double* cand;       // [G_NFIELDS][cstride]
@@ -344,7 +345,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
     for (int s = 0; s < M; ++s) {
         const int j = jbase + s * 64;
         valid[s] = j <= L;
-        eoff[s] = (unsigned)(valid[s] ? lo_abs + j - 1 : lo_abs) << 3;
+        eoff[s] = (unsigned)(valid[s] ? lo_abs + j - 1 : lo_abs) * (unsigned)(G_NFIELDS * 8);   // byte offset of the edge record
         const int ja = valid[s] ? lo_abs + j : lo_abs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) X[s].R[k] = P.pose0[(size_t)k * P.V + ja];
@@ -368,13 +369,13 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             }
     }
 
-    const unsigned fstride = (unsigned)P.estride << 3;
     auto opaque = [&]() {
 #pragma unroll
         for (int s = 0; s < M; ++s) asm volatile("" : "+v"(eoff[s]));
     };
     auto ldc = [&](int field, int s) -> double {
-        const char* fb = reinterpret_cast<const char*>(P.chain) + (size_t)field * fstride;
+        // record-major copy: one per-slot offset, the field is a compile-time displacement
+        const char* fb = reinterpret_cast<const char*>(P.chain_rec) + field * 8;
         return *reinterpret_cast<const double*>(fb + eoff[s]);
     };
     auto ld_rz = [&](int s, double* Rz, double* tz) {
