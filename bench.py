@@ -74,6 +74,10 @@ def build_workload(name):
         g = synth.inject_outliers(synth._se2_graph(700, 60, seed=7, laps=4.0), 300, seed=70)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=60)
         desc = "SE2 synthetic (V=700, 60 true loops) + 300 injected outliers"
+    elif name == "T2400":     # long trajectory: chains up to ~2400 poses, the chain no longer fits the LDS window
+        g = synth.inject_outliers(synth._se2_graph(2400, 40, seed=9, laps=14.0, name="long"), 200, seed=24)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=40)
+        desc = "SE2 synthetic (V=2400, 40 true loops) + 200 injected outliers"
     elif name == "tiny":
         g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)
@@ -188,7 +192,7 @@ def main():
         import csv
         f = w = 0.0
         for r in csv.DictReader(open(pmc_csv)):
-            if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_pair_kernel")):
+            if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_pair_kernel", "_group_kernel")):
                 if r["counter"] == "FETCH_SIZE":
                     f += float(r["sum_value"])
                 elif r["counter"] == "WRITE_SIZE":
@@ -201,7 +205,7 @@ def main():
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
                                 "L2-resident" % args.workload,
                 "kernel": "se%d_cells_kernel<W,M,NL>%s (%d launches per step, one per chain-length bin and loop count)" % (
-                    g.dim, " + se2_wave_kernel<M,NL,STAGED> + se2_pair_kernel<M,NL,STAGED>" if g.dim == 2 else "", launches),
+                    g.dim, " + se2_wave_kernel<M,NL,STAGED> + se2_group_kernel<W,M,NL,STAGED>" if g.dim == 2 else "", launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": float((L * cells["iterations"]).sum()),

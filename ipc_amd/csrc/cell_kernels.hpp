@@ -1,5 +1,5 @@
 // Launch interface of the cell-solver kernels.  The kernels are heavily templated, so they live
-// in their own translation units (se2_block.hip, se2_wave.hip, se2_pair.hip, se3_block.hip) that are compiled
+// in their own translation units (se2_block.hip, se2_wave.hip, se2_pair.hip, se2_quad.hip, se3_block.hip) that are compiled
 // in parallel and linked into libipc_amd.so; engine.hip only sees these prototypes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,6 +56,13 @@ static const int kPairM[] = {5, 7, 9, 11};
 constexpr int kNumPairM = sizeof(kPairM) / sizeof(kPairM[0]);
 constexpr int kPairVariantBase = 200;
 hipError_t launch_se2_pair(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
+                           SolveParams prm, CellOut out, unsigned* counter, int n_cu);
+
+// ---- quad kernels (SE2): the four waves of a workgroup on one cell; capacity 256*M ----
+static const int kQuadM[] = {7, 9, 11, 13};
+constexpr int kNumQuadM = sizeof(kQuadM) / sizeof(kQuadM[0]);
+constexpr int kQuadVariantBase = 300;
+hipError_t launch_se2_quad(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells,
                            SolveParams prm, CellOut out, unsigned* counter, int n_cu);
 
 }  // namespace ipc

@@ -336,10 +336,11 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // Chain-length bins: each bin is served by one (W, M) kernel variant.  The policy string
 // (env IPC_SE2_POLICY, default below) lists the variants to use as "WxM" tokens (block kernel, W
 // waves per cell, M poses per lane), "wM" tokens (SE2 wave kernel, one wave per cell, M poses per
-// lane) or "pM" tokens (SE2 pair kernel, two waves per cell); a cell goes to the listed variant of
+// lane), "pM" tokens (SE2 pair kernel, two waves per cell) or "qM" tokens (SE2 quad kernel, four
+// waves per cell); a cell goes to the listed variant of
 // smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
-static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,8x3,16x2,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
@@ -361,6 +362,9 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
         } else if (dim == 2 && sscanf(tok.c_str(), "p%d", &m) == 1) {   // pair kernel, two waves per cell
             w = 2;
             for (int k = 0; k < kNumPairM; ++k) if (kPairM[k] == m) v = kPairVariantBase + m;
+        } else if (dim == 2 && sscanf(tok.c_str(), "q%d", &m) == 1) {   // quad kernel, four waves per cell
+            w = 4;
+            for (int k = 0; k < kNumQuadM; ++k) if (kQuadM[k] == m) v = kQuadVariantBase + m;
         } else {
             if (sscanf(tok.c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
             for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
@@ -675,7 +679,10 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             const int var = h->plan.variant[b];
             hipError_t e;
             if (h->dim == 2)
-                e = var >= kPairVariantBase
+                e = var >= kQuadVariantBase
+                        ? launch_se2_quad(nl, var - kQuadVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                                          h->d_wave_ctr + s, h->n_cu)
+                    : var >= kPairVariantBase
                         ? launch_se2_pair(nl, var - kPairVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
                     : var >= kWaveVariantBase

@@ -1,0 +1,22 @@
+// Quad kernels of the SE(2) cell solver: the four waves of a workgroup on one cell
+// (se2_group_kernel.hpp with W = 4), for chains beyond what a wave pair holds in registers.
+#include "se2_group_kernel.hpp"
+
+namespace ipc {
+hipError_t launch_se2_quad(int nl, int M, int n, hipStream_t st, const Se2View& P, const int2* cells, SolveParams prm,
+                           CellOut out, unsigned* counter, int n_cu)
+{
+#define IPC_PCASE(MM)                                                                              \
+    case MM:                                                                                       \
+        return nl == 1 ? launch_group<4, MM, 1>(n, st, P, cells, prm, out, counter, n_cu)          \
+                       : launch_group<4, MM, 2>(n, st, P, cells, prm, out, counter, n_cu);
+    switch (M) {
+        IPC_PCASE(7)
+        IPC_PCASE(9)
+        IPC_PCASE(11)
+        IPC_PCASE(13)
+        default: return hipErrorInvalidValue;
+    }
+#undef IPC_PCASE
+}
+}  // namespace ipc

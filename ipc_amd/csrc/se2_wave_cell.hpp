@@ -34,8 +34,8 @@ struct WaveScratch {          // per cell (one wave, or a pair of waves), LDS
     LoopConst lc[NL];
     LoopState ls[2][NL];
     double lvec[NL][2][3];
-    double red[2][32];        // wide reduction, one row per wave of the cell
-    double gam[2][NL * 9];    // Gamma_l of the capacitance assembly (each wave keeps its own copy)
+    double red[4][32];        // wide reduction, one row per wave of the cell
+    double gam[4][NL * 9];    // Gamma_l of the capacitance assembly (each wave keeps its own copy)
 };
 
 // Mailbox of a wave pair that solves one cell together (W == 2).  The two waves run on different
@@ -44,8 +44,8 @@ struct WaveScratch {          // per cell (one wave, or a pair of waves), LDS
 // buffered on the sequence parity.  LDS operations of one wave complete in order, so the data is
 // visible before the flag.
 struct PairBox {
-    double data[2][2][8];     // [wave of the pair][parity][value]
-    int flag[2];
+    double data[4][2][8];     // [wave of the cell][parity][value]
+    int flag[4];
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -126,17 +126,18 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                                WaveScratch<NL>& sh, const double* cst, int wlo, int wstride, CellResult& res,
                                PairBox* box = nullptr, int seq0 = 0, int* seq_out = nullptr)
 {
-    static_assert(W == 1 || W == 2, "one wave or a pair of waves per cell");
+    static_assert(W == 1 || W == 2 || W == 4, "one, two or four cooperating waves per cell");
     constexpr int NS = NL * 3;
     const int lane = threadIdx.x & 63;
-    const int wsub = W == 2 ? ((threadIdx.x >> 6) & 1) : 0;      // wave of the pair
+    const int wsub = W > 1 ? ((threadIdx.x >> 6) & (W - 1)) : 0;  // wave of the cell
     const int gl = wsub * 64 + lane;                 // lane index within the cell
     const int j0 = gl * M + 1;                       // pose index of slot 0
 
-    // ---- pair exchange (W == 2): up to 8 doubles each way; also the pair's barrier ----
+    // ---- exchange among the W waves of the cell: every wave posts up to 8 doubles and waits for
+    // all others; peer(o, k) then reads wave o's value k.  Also the cell's barrier. ----
     int seq = seq0;
-    auto xchg = [&](const double (&mine)[8], int n, double (&theirs)[8]) {
-        if constexpr (W == 2) {
+    auto post_wait = [&](const double (&mine)[8], int n) {
+        if constexpr (W > 1) {
             ++seq;
             double* my = box->data[wsub][seq & 1];
             if (lane == 0) {
@@ -145,58 +146,55 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             }
             wave_sync();
             if (lane == 0) __hip_atomic_store(&box->flag[wsub], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(&box->flag[wsub ^ 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
-                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int o = 0; o < W; ++o) {
+                if (o == wsub) continue;
+                while (__hip_atomic_load(&box->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
+                    __builtin_amdgcn_s_sleep(1);
+            }
             wave_sync();
-            const double* th = box->data[wsub ^ 1][seq & 1];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) theirs[k] = k < n ? th[k] : 0.0;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) theirs[k] = 0.0;
         }
     };
+    auto peer = [&](int o, int k) -> double { return box->data[o][seq & 1][k]; };
     auto pair_barrier = [&]() {
-        if constexpr (W == 2) { double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8]; xchg(a, 0, b); }
+        if constexpr (W > 1) { double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; post_wait(a, 0); }
     };
-    // sum over the cell of a per-lane value: wave 0's total + wave 1's, in that order on both
-    auto cell_sum = [&](double v) -> double {
-        const double t = wave_sum(v);
-        if constexpr (W == 2) {
-            double a[8] = {t, 0, 0, 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 1, b);
-            return wsub == 0 ? t + b[0] : b[0] + t;
-        }
-        return t;
-    };
+    // sums over the cell of per-lane values: the waves' totals added in wave order on every wave
     auto cell_sum2 = [&](double v0, double v1, double& s0, double& s1) {
         const double t0 = wave_sum(v0), t1 = wave_sum(v1);
-        if constexpr (W == 2) {
-            double a[8] = {t0, t1, 0, 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 2, b);
-            s0 = wsub == 0 ? t0 + b[0] : b[0] + t0;
-            s1 = wsub == 0 ? t1 + b[1] : b[1] + t1;
+        if constexpr (W > 1) {
+            double a[8] = {t0, t1, 0, 0, 0, 0, 0, 0};
+            post_wait(a, 2);
+            s0 = wsub == 0 ? t0 : peer(0, 0);
+            s1 = wsub == 0 ? t1 : peer(0, 1);
+#pragma unroll
+            for (int o = 1; o < W; ++o) { s0 += o == wsub ? t0 : peer(o, 0); s1 += o == wsub ? t1 : peer(o, 1); }
         } else { s0 = t0; s1 = t1; }
     };
     // exclusive prefix over the cell's lanes of a per-lane total
     auto cell_excl = [&](double run) -> double {
         const double inc = wave_inclusive_scan(run);
         double off = inc - run;
-        if constexpr (W == 2) {
-            double a[8] = {read_lane(inc, 63), 0, 0, 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 1, b);
-            if (wsub == 1) off += b[0];
+        if constexpr (W > 1) {
+            double a[8] = {read_lane(inc, 63), 0, 0, 0, 0, 0, 0, 0};
+            post_wait(a, 1);
+            double lower = 0.0;
+#pragma unroll
+            for (int o = 0; o < W - 1; ++o) if (o < wsub) lower += peer(o, 0);
+            off += lower;
         }
         return off;
     };
-
     auto cell_excl2 = [&](double r0, double r1, double& o0, double& o1) {
         const double i0 = wave_inclusive_scan(r0), i1 = wave_inclusive_scan(r1);
         o0 = i0 - r0; o1 = i1 - r1;
-        if constexpr (W == 2) {
-            double a[8] = {read_lane(i0, 63), read_lane(i1, 63), 0, 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 2, b);
-            if (wsub == 1) { o0 += b[0]; o1 += b[1]; }
+        if constexpr (W > 1) {
+            double a[8] = {read_lane(i0, 63), read_lane(i1, 63), 0, 0, 0, 0, 0, 0};
+            post_wait(a, 2);
+            double l0 = 0.0, l1 = 0.0;
+#pragma unroll
+            for (int o = 0; o < W - 1; ++o) if (o < wsub) { l0 += peer(o, 0); l1 += peer(o, 1); }
+            o0 += l0; o1 += l1;
         }
     };
 
@@ -317,11 +315,11 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     // pair's second wave: lane 63 of the first, through the mailbox)
     auto prev0 = [&](const Pose2& last) -> Pose2 {
         Pose2 cr = gauge;
-        if constexpr (W == 2) {
+        if constexpr (W > 1) {
             double a[8] = {read_lane(last.x, 63), read_lane(last.y, 63), read_lane(last.th, 63), read_lane(last.c, 63),
-                           read_lane(last.s, 63), 0, 0, 0}, b[8];
-            xchg(a, 5, b);
-            if (wsub == 1) { cr.x = b[0]; cr.y = b[1]; cr.th = b[2]; cr.c = b[3]; cr.s = b[4]; }
+                           read_lane(last.s, 63), 0, 0, 0};
+            post_wait(a, 5);
+            if (wsub > 0) { cr.x = peer(wsub - 1, 0); cr.y = peer(wsub - 1, 1); cr.th = peer(wsub - 1, 2); cr.c = peer(wsub - 1, 3); cr.s = peer(wsub - 1, 4); }
         }
         Pose2 p;
         p.x = lane_prev(last.x, cr.x); p.y = lane_prev(last.y, cr.y); p.th = lane_prev(last.th, cr.th);
@@ -331,19 +329,19 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     // 3-vector of the lane below / above across the pair (0 at the ends of the cell)
     auto prev3 = [&](double vx, double vy, double vth, double& ox, double& oy, double& oth) {
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-        if constexpr (W == 2) {
-            double a[8] = {read_lane(vx, 63), read_lane(vy, 63), read_lane(vth, 63), 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 3, b);
-            if (wsub == 1) { c0 = b[0]; c1 = b[1]; c2 = b[2]; }
+        if constexpr (W > 1) {
+            double a[8] = {read_lane(vx, 63), read_lane(vy, 63), read_lane(vth, 63), 0, 0, 0, 0, 0};
+            post_wait(a, 3);
+            if (wsub > 0) { c0 = peer(wsub - 1, 0); c1 = peer(wsub - 1, 1); c2 = peer(wsub - 1, 2); }
         }
         ox = lane_prev(vx, c0); oy = lane_prev(vy, c1); oth = lane_prev(vth, c2);
     };
     auto next3 = [&](double vx, double vy, double vth, double& ox, double& oy, double& oth) {
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-        if constexpr (W == 2) {
-            double a[8] = {read_lane(vx, 0), read_lane(vy, 0), read_lane(vth, 0), 0, 0, 0, 0, 0}, b[8];
-            xchg(a, 3, b);
-            if (wsub == 0) { c0 = b[0]; c1 = b[1]; c2 = b[2]; }
+        if constexpr (W > 1) {
+            double a[8] = {read_lane(vx, 0), read_lane(vy, 0), read_lane(vth, 0), 0, 0, 0, 0, 0};
+            post_wait(a, 3);
+            if (wsub < W - 1) { c0 = peer(wsub + 1, 0); c1 = peer(wsub + 1, 1); c2 = peer(wsub + 1, 2); }
         }
         ox = lane_next(vx, c0); oy = lane_next(vy, c1); oth = lane_next(vth, c2);
     };
@@ -478,7 +476,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         }
         if (MODE == 2) return 0.0;
         wave_sync();
-        if constexpr (W == 2) {
+        if constexpr (W > 1) {
             // one exchange: the partial sums of both waves; it also tells each wave that the
             // partner's loop end points are in place, so the loops are evaluated after it (by both
             // waves, same values; the first wave's lanes store the loop state)
@@ -666,7 +664,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             // VGPRs while the whole chain state is live):
             //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> gam[.]
             //   lane r*(NS+1)+c  : S[r][c] (c < NS) / rhs d[r] (c == NS), then Gauss-Jordan in place
-            auto wtv = [&](int k) -> double { return W == 2 ? sh.red[0][k] + sh.red[1][k] : sh.red[0][k]; };
+            auto wtv = [&](int k) -> double {
+                double t = sh.red[0][k];
+#pragma unroll
+                for (int o = 1; o < W; ++o) t += sh.red[o][k];
+                return t;
+            };
             double* gamw = sh.gam[wsub];
             if (lane < NL * 9) {
                 const int l = lane / 9, i = (lane % 9) / 3, a = lane % 3;
@@ -903,11 +906,15 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     }
     mx = wave_max(mx);
     nan = __ballot(nan) != 0ull;
-    if constexpr (W == 2) {
-        double a[8] = {mx, nan ? 1.0 : 0.0, 0, 0, 0, 0, 0, 0}, b[8];
-        xchg(a, 2, b);
-        mx = fmax(mx, b[0]);
-        nan = nan || b[1] != 0.0;
+    if constexpr (W > 1) {
+        double a[8] = {mx, nan ? 1.0 : 0.0, 0, 0, 0, 0, 0, 0};
+        post_wait(a, 2);
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            if (o == wsub) continue;
+            mx = fmax(mx, peer(o, 0));
+            nan = nan || peer(o, 1) != 0.0;
+        }
     }
     wave_sync();
 #pragma unroll

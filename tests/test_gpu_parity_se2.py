@@ -288,13 +288,13 @@ def test_matrix_mode_vs_faithful_incremental_mode(oracle):
 
 
 def test_kernel_families_agree_with_each_other(oracle, monkeypatch):
-    """The same cells through the wave kernels, the pair kernels and the block kernels: identical
+    """The same cells through the wave kernels, the pair and quad kernels and the block kernels: identical
     decisions, chi2 equal to round-off (they share the mathematics, not the summation order)."""
     from ipc_amd import synth
     g = synth.inject_outliers(synth._se2_graph(640, 40, seed=21, laps=4.0, name="fam"), 60, seed=8)
     results = {}
-    for name, pol in (("wave", "w1,w3,w5,w7,w9,w11,w13"), ("pair", "p5,p7,p9,p11"), ("block", "2x1,4x1,8x1,8x2,16x2"),
-                      ("default", None)):
+    for name, pol in (("wave", "w1,w3,w5,w7,w9,w11,w13"), ("pair", "p5,p7,p9,p11"), ("quad", "q7,q9,q11,q13"),
+                      ("block", "2x1,4x1,8x1,8x2,16x2"), ("default", None)):
         if pol is None:
             monkeypatch.delenv("IPC_SE2_POLICY", raising=False)
         else:
@@ -306,7 +306,7 @@ def test_kernel_families_agree_with_each_other(oracle, monkeypatch):
         results[name] = (bits.copy(), acc.copy(), c[order])
         eng.close()
     ref_bits, ref_acc, ref_cells = results["block"]
-    for name in ("wave", "pair", "default"):
+    for name in ("wave", "pair", "quad", "default"):
         bits, acc, cells = results[name]
         assert np.array_equal(bits, ref_bits), name
         assert np.array_equal(acc, ref_acc), name
