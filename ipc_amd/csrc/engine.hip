@@ -341,6 +341,7 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // smallest capacity 64*W*M that holds it.
 struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
 static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
+static const int kDefaultSideStreams = 3;
 static const char* kDefaultPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
@@ -405,6 +406,12 @@ struct ipc_engine {
     double *d_chi = nullptr, *d_chitot = nullptr; int4* d_meta = nullptr;
     int last_cells = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false; int last_launches = 0;
+    // side streams: the bin launches of one solve are spread over them so that the tail of one
+    // launch (a few cells that run to the iteration cap) overlaps the next bins
+    static constexpr int kMaxSide = 7;
+    int n_side = 0;
+    hipStream_t side[kMaxSide] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
     // scratch for ipc_run
     unsigned long long *d_upper = nullptr, *d_bits = nullptr; unsigned char* d_acc = nullptr; size_t run_cap = 0;
     // incremental mode / final map (SE2)
@@ -445,6 +452,17 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    {
+        const char* env = getenv("IPC_SIDE_STREAMS");
+        h->n_side = env && *env ? atoi(env) : kDefaultSideStreams;
+        if (h->n_side < 0) h->n_side = 0;
+        if (h->n_side > ipc_engine::kMaxSide) h->n_side = ipc_engine::kMaxSide;
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int k = 0; k < h->n_side; ++k) {
+            HIPCHK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+        }
+    }
     HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * (nf * (size_t)h->estride + 64)));   // + read-ahead padding
     HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * ps * (size_t)n_vertices));
     HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1)));
@@ -510,6 +528,11 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     delete h->cluster3;
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < h->n_side; ++k) {
+        if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+        if (h->side[k]) hipStreamDestroy(h->side[k]);
+    }
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return IPC_OK;
@@ -671,29 +694,39 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     int launches = 0;
     HIPCHK(hipMemsetAsync(h->d_wave_ctr, 0, sizeof(unsigned) * NS, st));
     HIPCHK(hipEventRecord(h->ev0, st));
+    if (h->n_side) {
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        for (int k = 0; k < h->n_side; ++k) HIPCHK(hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
+    }
     for (int b = nb - 1; b >= 0; --b) {
         for (int nl = 2; nl >= 1; --nl) {
             const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
             const int var = h->plan.variant[b];
+            const int lane_q = launches % (h->n_side + 1);
+            hipStream_t ls = lane_q == 0 ? st : h->side[lane_q - 1];
             hipError_t e;
             if (h->dim == 2)
                 e = var >= kQuadVariantBase
-                        ? launch_se2_quad(nl, var - kQuadVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                        ? launch_se2_quad(nl, var - kQuadVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
                     : var >= kPairVariantBase
-                        ? launch_se2_pair(nl, var - kPairVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                        ? launch_se2_pair(nl, var - kPairVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
                     : var >= kWaveVariantBase
-                        ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out,
+                        ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
-                        : launch_se2_block(nl, var, (int)counts[s], st, P, h->d_cells + offsets[s], sp, out);
+                        : launch_se2_block(nl, var, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out);
             else
-                e = launch_se3_block(nl, var, (int)counts[s], st, P3, h->d_cells + offsets[s], sp, out);
+                e = launch_se3_block(nl, var, (int)counts[s], ls, P3, h->d_cells + offsets[s], sp, out);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }
+    }
+    for (int k = 0; k < h->n_side; ++k) {
+        HIPCHK(hipEventRecord(h->ev_join[k], h->side[k]));
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join[k], 0));
     }
     HIPCHK(hipEventRecord(h->ev1, st));
     h->ev_valid = true;
