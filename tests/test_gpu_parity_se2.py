@@ -313,3 +313,24 @@ def test_kernel_families_agree_with_each_other(oracle, monkeypatch):
         assert np.array_equal(cells["i"], ref_cells["i"]) and np.array_equal(cells["j"], ref_cells["j"])
         a, b = cells["max_chi2"], ref_cells["max_chi2"]
         assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-12)), name
+
+
+def test_side_streams_do_not_change_results(oracle, monkeypatch):
+    """The bin launches of a solve are spread over side streams (IPC_SIDE_STREAMS); the cells and
+    kernels are the same, so every result is bit-identical to the single-stream run."""
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth._se2_graph(640, 40, seed=22, laps=4.0, name="ss"), 60, seed=9)
+    res = {}
+    for n in ("0", "3", "7"):
+        monkeypatch.setenv("IPC_SIDE_STREAMS", n)
+        eng, cfg = _engine(g)
+        bits, acc = eng.run()
+        c = eng.cell_info()
+        order = np.lexsort((c["j"], c["i"]))
+        res[n] = (bits.copy(), acc.copy(), c[order])
+        eng.close()
+    for n in ("3", "7"):
+        assert np.array_equal(res[n][0], res["0"][0])
+        assert np.array_equal(res[n][1], res["0"][1])
+        assert np.array_equal(res[n][2]["max_chi2"], res["0"][2]["max_chi2"])
+        assert np.array_equal(res[n][2]["iterations"], res["0"][2]["iterations"])
