@@ -135,6 +135,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 
     // ---- exchange among the W waves of the cell: every wave posts up to 8 doubles and waits for
     // all others; peer(o, k) then reads wave o's value k.  Also the cell's barrier. ----
+#ifdef IPC_PHASE_TIMING
+    unsigned long long tmA = 0, tmB1 = 0, tmB2 = 0, tmC = 0, tmT = 0, tmW = 0, tm0 = __builtin_amdgcn_s_memtime();
+#define IPC_WTICK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tm0; tm0 = t_; }
+#else
+#define IPC_WTICK(acc)
+#endif
     int seq = seq0;
     auto post_wait = [&](const double (&mine)[8], int n) {
         if constexpr (W > 1) {
@@ -146,12 +152,18 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             }
             wave_sync();
             if (lane == 0) __hip_atomic_store(&box->flag[wsub], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef IPC_PHASE_TIMING
+            const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
             for (int o = 0; o < W; ++o) {
                 if (o == wsub) continue;
                 while (__hip_atomic_load(&box->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
                     __builtin_amdgcn_s_sleep(1);
             }
+#ifdef IPC_PHASE_TIMING
+            tmW += __builtin_amdgcn_s_memtime() - tw0;
+#endif
             wave_sync();
         }
     };
@@ -505,6 +517,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     const int maxTrials = 100;
     int it_done = 0, tries_total = 0, flags = 0;
 
+    IPC_WTICK(tmT)
     for (int it = 0; it < iterations; ++it) {
         // ---- phase A: forces g, hand-back m -> b ----
         opaque();
@@ -572,6 +585,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 IPC_SLOT_FENCE();
             }
         }
+        IPC_WTICK(tmA)
         // ---- phase B: b^T b, b^T H b, capacitance partials, solve ----
         double bb, bHb, alpha, hsdNorm;
         double nu[NL][3];
@@ -660,6 +674,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             if constexpr (NL == 2) wave_sum16_store(v2, &sh.red[wsub][16]);
             wave_sync();
             pair_barrier();                           // both waves' partial sums and end-point vectors are in place
+            IPC_WTICK(tmB1)
             // ---- capacitance solve, lane-parallel (a uniform 6x6 solve in registers would pin ~150
             // VGPRs while the whole chain state is live):
             //   lane l*9+i*3+a   : Gamma_l[i][a]                              -> gam[.]
@@ -743,6 +758,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             alpha = bb / bHb;
             hsdNorm = sqrt(alpha * alpha * bb);
         }
+        IPC_WTICK(tmB2)
         // ---- phase C: u, rho, prefix sums -> h_gn; |h|^2, b.h (h^T H h = b.h) ----
         double hgnNorm, bh, hHh;
         opaque();
@@ -815,6 +831,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             hgnNorm = sqrt(hh);
             hHh = bh;
         }
+        IPC_WTICK(tmC)
         // ---- trial loop ----
         bool goodStep = false;
         int numTries = 0;
@@ -883,8 +900,19 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         } while (!goodStep && numTries < maxTrials);
         it_done = it + 1;
         tries_total += numTries;
+        IPC_WTICK(tmT)
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }
     }
+#ifdef IPC_PHASE_TIMING
+    if (lane == 0 && wsub == 0 && P.dbg) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(P.dbg) + 64 + 16 * (M + 16 * (W - 1));
+        atomicAdd(d + 0, tmA); atomicAdd(d + 1, tmB1); atomicAdd(d + 2, tmB2); atomicAdd(d + 3, tmC);
+        atomicAdd(d + 4, tmT); atomicAdd(d + 5, tmW);
+        atomicAdd(d + 6, (unsigned long long)it_done); atomicAdd(d + 7, (unsigned long long)evals);
+        atomicAdd(d + 8, (unsigned long long)it_done * (unsigned long long)L);
+        atomicAdd(d + 9, 1ull);
+    }
+#endif
 
     // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
     double mx = 0.0;
