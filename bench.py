@@ -70,6 +70,10 @@ def build_workload(name):
         g = g2
         cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=60)
         desc = "small sphere SE3 synthetic (V=500, 60 true loops) + 60 injected outliers"
+    elif name == "C5":        # BASELINE configs[4] on one GPU (the driver shards it over 8): bounded loop spans
+        g = synth.inject_outliers(synth.chain3d(), 20000, seed=20000, local=True)
+        cfg = Config(6.251, 50, 6.251, 100, 50.0, canonic_inliers=5000)
+        desc = "synthetic SE3 chain (V=50000, 5000 true loops of span <= 200) + 20000 injected local outliers"
     elif name == "T700":      # every chain <= 699 poses: one kernel variant can take all cells (variant A/B timing)
         g = synth.inject_outliers(synth._se2_graph(700, 60, seed=7, laps=4.0), 300, seed=70)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=60)

@@ -33,7 +33,8 @@ static const Variant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static const Variant kVariants3[] = { {1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4},
-                                      {4, 2}, {4, 4}, {8, 2}, {8, 4}, {4, 8}, {8, 5} };
+                                      {4, 2}, {4, 4}, {8, 2}, {8, 4}, {4, 8}, {8, 5},
+                                      {1, 2}, {2, 2}, {1, 4}, {2, 4}, {1, 3}, {2, 3} };
 constexpr int kNumVariants3 = sizeof(kVariants3) / sizeof(kVariants3[0]);
 
 hipError_t launch_se2_block(int nl, int variant, int n, hipStream_t st, const Se2View& P, const int2* cells,

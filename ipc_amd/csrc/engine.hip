@@ -339,10 +339,19 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
 // lane), "pM" tokens (SE2 pair kernel, two waves per cell) or "qM" tokens (SE2 quad kernel, four
 // waves per cell); a cell goes to the listed variant of
 // smallest capacity 64*W*M that holds it.
-struct BinPlan { BinCaps caps; int variant[kMaxBins]; };
+struct BinPlan {
+    BinCaps caps;
+    int variant[kMaxBins];
+    // SE3: variant for a bin with too few cells to fill the GPU (more waves per cell, so the few
+    // cells finish sooner), and the cell count below which it is used
+    int latency_variant[kMaxBins];
+    int latency_below[kMaxBins];
+};
 static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
 static const int kDefaultSideStreams = 3;
-static const char* kDefaultPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
+static const char* kDefaultPolicy3 = "1x1,1x2,1x3,2x2,2x3,4x2,4x4,8x4,8x5,16x4";
+// SE3 variants for thin bins, by capacity (IPC_SE3_LATENCY_POLICY; "none" disables the switch)
+static const char* kDefaultLatencyPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
     const char* env = getenv(dim == 2 ? "IPC_SE2_POLICY" : "IPC_SE3_POLICY");
@@ -380,6 +389,39 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
     for (int b = 0; b < kMaxBins; ++b) {
         bp.caps.cap[b] = b < bp.caps.n ? items[b].first : 0;
         bp.variant[b] = b < bp.caps.n ? items[b].second : -1;
+        bp.latency_variant[b] = -1;
+        bp.latency_below[b] = 0;
+    }
+    if (dim == 3) {
+        const char* lenv = getenv("IPC_SE3_LATENCY_POLICY");
+        const std::string lpol = lenv && *lenv ? lenv : kDefaultLatencyPolicy3;
+        if (lpol != "none") {
+            size_t lp = 0;
+            std::vector<std::pair<int, int>> lat;       // (cap, variant)
+            while (lp < lpol.size()) {
+                size_t e = lpol.find(',', lp);
+                if (e == std::string::npos) e = lpol.size();
+                int w = 0, m = 0, v = -1;
+                if (sscanf(lpol.substr(lp, e - lp).c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE3_LATENCY_POLICY token"; return false; }
+                for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
+                if (v < 0) { err = "IPC_SE3_LATENCY_POLICY names a variant that is not compiled"; return false; }
+                lat.push_back({64 * w * m, v});
+                lp = e + 1;
+            }
+            std::sort(lat.begin(), lat.end());
+            for (int b = 0; b < bp.caps.n; ++b) {
+                const int wt = table[bp.variant[b]].W;
+                for (const auto& lv : lat) {
+                    if (lv.first < bp.caps.cap[b]) continue;
+                    // only a variant with more waves per cell is a latency variant
+                    if (table[lv.second].W > wt) {
+                        bp.latency_variant[b] = lv.second;
+                        bp.latency_below[b] = wt <= 4 ? 4 / wt : 1;      // x CUs at launch time
+                    }
+                    break;
+                }
+            }
+        }
     }
     return true;
 }
@@ -703,7 +745,9 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
-            const int var = h->plan.variant[b];
+            int var = h->plan.variant[b];
+            if (h->plan.latency_variant[b] >= 0 && (int)counts[s] < h->plan.latency_below[b] * h->n_cu)
+                var = h->plan.latency_variant[b];
             const int lane_q = launches % (h->n_side + 1);
             hipStream_t ls = lane_q == 0 ? st : h->side[lane_q - 1];
             hipError_t e;

@@ -52,6 +52,12 @@ static hipError_t launch_se3(int variant, int n, hipStream_t st, const Se3View& 
         IPC_CASE3(10, 8, 4)
         IPC_CASE3(11, 4, 8)
         IPC_CASE3(12, 8, 5)
+        IPC_CASE3(13, 1, 2)
+        IPC_CASE3(14, 2, 2)
+        IPC_CASE3(15, 1, 4)
+        IPC_CASE3(16, 2, 4)
+        IPC_CASE3(17, 1, 3)
+        IPC_CASE3(18, 2, 3)
         default: return hipErrorInvalidValue;
     }
 #undef IPC_CASE3

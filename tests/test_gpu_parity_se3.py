@@ -66,3 +66,40 @@ def test_medium_sphere_sampled_cells(oracle, seed):
     C = unpack_bits(bits, eng.N)
     assert np.array_equal(C, C.T)
     assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
+
+
+def test_c5_like_long_trajectory_bounded_spans(oracle):
+    """BASELINE configs[4] at reduced size: a long SE(3) trajectory (V = 4000) whose true loops and
+    local outliers all have bounded spans, so almost every pair of candidates is disjoint (free
+    cells, AND of the diagonals) and the solved cells are short chains."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import unpack_bits
+    O = oracle
+    g = synth.chain3d(seed=5, V=4000, n_loops=300, max_span=200)
+    g = synth.inject_outliers(g, 1200, seed=5, local=True)
+    eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+    bits, acc = eng.run()
+    cells = eng.cell_info()
+    n_all = eng.N * (eng.N + 1) // 2
+    assert eng.N == 1500 and len(cells) < n_all // 10          # sparse: most cells are free
+    poses = O.propagate(3, g.odom_meas)
+    order = np.argsort(cells["hi"] - cells["lo"])
+    rng = np.random.default_rng(3)
+    pick = np.unique(np.concatenate([order[-6:], rng.choice(order, 40, replace=False)]))
+    for c in cells[pick]:
+        solved, mx, _ = O.pair_cell(3, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids, g.loop_meas,
+                                    g.loop_info, int(c["i"]), int(c["j"]), cfg.fast_reject_iter_base,
+                                    cfg.slow_reject_iter_base)
+        assert solved
+        th = cfg.fast_reject_th if c["i"] == c["j"] else cfg.slow_reject_th
+        assert (not (mx > th)) == (not (c["max_chi2"] > th)), (c, mx)
+        assert abs(mx - c["max_chi2"]) <= 1e-5 * max(abs(mx), 1e-12), (c, mx)
+    C = unpack_bits(bits, eng.N)
+    assert np.array_equal(C, C.T)
+    # free cells: disjoint candidates agree iff both pass on their own (reference consensus.cpp:121-160)
+    d = np.diag(C).astype(bool)
+    lo = np.minimum(g.loop_ids[:, 0], g.loop_ids[:, 1])
+    hi = np.maximum(g.loop_ids[:, 0], g.loop_ids[:, 1])
+    disjoint = (hi[:, None] <= lo[None, :]) | (hi[None, :] <= lo[:, None])
+    assert np.array_equal(C[disjoint].astype(bool), (d[:, None] & d[None, :])[disjoint])
+    assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
