@@ -13,6 +13,8 @@ The `backend` object is what does the solving: in production it is the HIP engin
 the same shard layout, which is how the sharding / gather / reassembly logic is covered
 without a GPU.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -25,6 +27,14 @@ class EngineBackend:
         self.e = engine
         self.device = torch.device("cuda", engine.device)
         self.N, self.words = engine.N, engine.words
+        # A stream of its own, made torch's current stream for the duration of a step: torch's
+        # default stream is the NULL stream, whose handle (0) the C ABI reads as "the engine's own
+        # non-blocking stream" -- work launched there is NOT ordered with the collective, which
+        # torch orders against its current stream.
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
 
     def empty_words(self, n):
         return torch.empty(n, dtype=torch.int64, device=self.device)
@@ -33,7 +43,10 @@ class EngineBackend:
         return torch.empty(n, dtype=torch.uint8, device=self.device)
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        h = torch.cuda.current_stream(self.device).cuda_stream
+        if not h:
+            raise RuntimeError("EngineBackend must run under its own stream (use stream_ctx())")
+        return h
 
     def solve_rows(self, rank, world, upper):
         self.e.solve_rows(rank, world, upper.data_ptr(), self._stream())
@@ -56,14 +69,19 @@ class ShardedMatrix:
         self.accepted = backend.empty_bytes(N)
 
     def step(self):
-        """One pass of the hot path: solve my rows, all-gather, assemble, set-max."""
-        self.b.solve_rows(self.rank, self.world, self.upper)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.upper, group=self.group)
-        self.b.assemble(self.gathered, self.world, self.bits)
-        self.b.set_max(self.bits, self.accepted)
+        """One pass of the hot path: solve my rows, all-gather, assemble, set-max; everything is
+        enqueued on the backend's stream (the collective is ordered against it by torch)."""
+        ctx = self.b.stream_ctx() if hasattr(self.b, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            self.b.solve_rows(self.rank, self.world, self.upper)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.gathered, self.upper, group=self.group)
+            self.b.assemble(self.gathered, self.world, self.bits)
+            self.b.set_max(self.bits, self.accepted)
 
     def result(self):
         N, words = self.b.N, self.b.words
+        if hasattr(self.b, "stream"):
+            self.b.stream.synchronize()
         bits = self.bits.cpu().numpy().view(np.uint64).reshape(N, words)
         return bits, self.accepted.cpu().numpy()
