@@ -15,7 +15,9 @@
  *   - vertex ids are 0..V-1 and odometry edge j joins vertex j -> j+1 (the reference's own
  *     contract, src/consensus.cpp:13-23).
  *   - pointers named d_* are DEVICE pointers (HBM of the engine's GPU), everything else is
- *     host memory.  `stream` is a hipStream_t passed as void* (NULL = the engine's own stream).
+ *     host memory.  `stream` is a hipStream_t passed as void* (NULL = the engine's own
+ *     NON-BLOCKING stream, which is not ordered with the legacy default stream: pass an explicit
+ *     stream when other work, e.g. a collective, must be ordered with the call).
  *   - a handle is bound to one GPU and must not be used from two threads at once (the
  *     reference's IPC object is not re-entrant either).
  */
