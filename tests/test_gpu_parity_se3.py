@@ -103,3 +103,32 @@ def test_c5_like_long_trajectory_bounded_spans(oracle):
     disjoint = (hi[:, None] <= lo[None, :]) | (hi[None, :] <= lo[:, None])
     assert np.array_equal(C[disjoint].astype(bool), (d[:, None] & d[None, :])[disjoint])
     assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
+
+
+def test_se3_variant_choice_does_not_change_decisions(oracle, monkeypatch):
+    """Thin bins switch to variants with more waves per cell (IPC_SE3_LATENCY_POLICY); with the switch
+    off, or with the former one-pose-per-lane bins, the decisions are the same and chi2 agrees to
+    round-off (different summation orders)."""
+    from ipc_amd import synth
+    g = synth.sphere_like(seed=203, rings=12, per_ring=30, radius=12.0)
+    g = synth.inject_outliers(g.subset(np.arange(0, g.N, 10)), 14, seed=3)
+    res = {}
+    for name, pol, lat in (("default", None, None), ("no-switch", None, "none"),
+                           ("one-pose", "1x1,2x1,4x1,4x2,4x4,8x4", "none")):
+        for var, val in (("IPC_SE3_POLICY", pol), ("IPC_SE3_LATENCY_POLICY", lat)):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
+        eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+        bits, acc = eng.run()
+        c = eng.cell_info()
+        res[name] = (bits.copy(), acc.copy(), c[np.lexsort((c["j"], c["i"]))])
+        eng.close()
+    ref = res["one-pose"]
+    for name in ("default", "no-switch"):
+        bits, acc, cells = res[name]
+        assert np.array_equal(bits, ref[0]), name
+        assert np.array_equal(acc, ref[1]), name
+        a, b = cells["max_chi2"], ref[2]["max_chi2"]
+        assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-12)), name
