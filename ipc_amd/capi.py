@@ -59,6 +59,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise IpcError("libipc_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
                        "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64; with this library loaded
+    # first the process binds /opt/rocm's copy and a later `import torch` finds no GPU.  Loading
+    # torch's runtime first (when torch is there) makes both share it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.ipc_last_error.restype = C.c_char_p
     vp, ip, dp = C.c_void_p, C.c_int, C.c_double

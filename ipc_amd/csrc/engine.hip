@@ -453,7 +453,7 @@ struct ipc_engine {
     static constexpr int kMaxSide = 7;
     int n_side = 0;
     hipStream_t side[kMaxSide] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {}, ev_join_own = nullptr;
     // scratch for ipc_run
     unsigned long long *d_upper = nullptr, *d_bits = nullptr; unsigned char* d_acc = nullptr; size_t run_cap = 0;
     // incremental mode / final map (SE2)
@@ -500,6 +500,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         if (h->n_side < 0) h->n_side = 0;
         if (h->n_side > ipc_engine::kMaxSide) h->n_side = ipc_engine::kMaxSide;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join_own, hipEventDisableTiming));
         for (int k = 0; k < h->n_side; ++k) {
             HIPCHK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
@@ -571,6 +572,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join_own) hipEventDestroy(h->ev_join_own);
     for (int k = 0; k < h->n_side; ++k) {
         if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
         if (h->side[k]) hipStreamDestroy(h->side[k]);
@@ -736,8 +738,15 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     int launches = 0;
     HIPCHK(hipMemsetAsync(h->d_wave_ctr, 0, sizeof(unsigned) * NS, st));
     HIPCHK(hipEventRecord(h->ev0, st));
+    // With side streams on, every bin launch goes to a stream the engine created itself (its own
+    // stream and the side streams, created together so that the runtime spreads them over different
+    // hardware queues); a caller's stream only forks and joins.  Launching a share of the bins on a
+    // caller's stream made the overlap depend on which hardware queue that stream happened to be
+    // mapped to (T700 on a torch pool stream: 51 ms instead of 32 ms).
+    hipStream_t st0 = h->n_side ? h->own_stream : st;
     if (h->n_side) {
         HIPCHK(hipEventRecord(h->ev_fork, st));
+        if (st0 != st) HIPCHK(hipStreamWaitEvent(st0, h->ev_fork, 0));
         for (int k = 0; k < h->n_side; ++k) HIPCHK(hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
     }
     for (int b = nb - 1; b >= 0; --b) {
@@ -749,7 +758,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             if (h->plan.latency_variant[b] >= 0 && (int)counts[s] < h->plan.latency_below[b] * h->n_cu)
                 var = h->plan.latency_variant[b];
             const int lane_q = launches % (h->n_side + 1);
-            hipStream_t ls = lane_q == 0 ? st : h->side[lane_q - 1];
+            hipStream_t ls = lane_q == 0 ? st0 : h->side[lane_q - 1];
             hipError_t e;
             if (h->dim == 2)
                 e = var >= kQuadVariantBase
@@ -767,6 +776,10 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }
+    }
+    if (st0 != st) {
+        HIPCHK(hipEventRecord(h->ev_join_own, st0));
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join_own, 0));
     }
     for (int k = 0; k < h->n_side; ++k) {
         HIPCHK(hipEventRecord(h->ev_join[k], h->side[k]));
