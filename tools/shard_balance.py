@@ -1,0 +1,35 @@
+"""Per-rank solve time of the row shards, emulated on ONE GPU (each rank's shard solved in turn;
+no collective): shows the load balance of the row-cyclic partition and the fixed per-step cost.
+usage: python tools/shard_balance.py [C2] [world ...]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from bench import build_workload
+from ipc_amd.consensus import IPC
+from ipc_amd.dist import EngineBackend
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
+worlds = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
+g, cfg, desc = build_workload(wl)
+eng = IPC(g, cfg, device=0)
+b = EngineBackend(eng)
+for world in worlds:
+    rpr = (eng.N + world - 1) // world
+    gathered = b.empty_words(world * rpr * eng.words)
+    bits, acc = b.empty_words(eng.N * eng.words), b.empty_bytes(eng.N)
+    times = []
+    for r in range(world):
+        upper = gathered[r * rpr * eng.words:(r + 1) * rpr * eng.words]
+        best = 1e9
+        for rep in range(2):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            with b.stream_ctx():
+                b.solve_rows(r, world, upper)
+                b.assemble(gathered, world, bits)
+                b.set_max(bits, acc)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+        times.append(best * 1e3)
+    print("world %d: per-rank step ms min %.1f max %.1f mean %.1f -> bound on the speed-up over world 1: %.2fx" % (
+        world, min(times), max(times), sum(times) / world, (t1 if world > 1 else max(times)) / max(times)))
+    if world == 1:
+        t1 = max(times)
