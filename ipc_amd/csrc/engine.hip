@@ -348,7 +348,9 @@ struct BinPlan {
     int latency_below[kMaxBins];
 };
 static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
-static const int kDefaultSideStreams = 3;
+// engine streams + the caller's stream = the runtime's four hardware queues for SE2; the long SE3
+// launches gain a little from a fourth engine stream
+static const int kDefaultSideStreams2 = 2, kDefaultSideStreams3 = 3;
 static const char* kDefaultPolicy3 = "1x1,1x2,1x3,2x2,2x3,4x2,4x4,8x4,8x5,16x4";
 // SE3 variants for thin bins, by capacity (IPC_SE3_LATENCY_POLICY; "none" disables the switch)
 static const char* kDefaultLatencyPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
@@ -496,7 +498,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipEventCreate(&h->ev1));
     {
         const char* env = getenv("IPC_SIDE_STREAMS");
-        h->n_side = env && *env ? atoi(env) : kDefaultSideStreams;
+        h->n_side = env && *env ? atoi(env) : (h->dim == 2 ? kDefaultSideStreams2 : kDefaultSideStreams3);
         if (h->n_side < 0) h->n_side = 0;
         if (h->n_side > ipc_engine::kMaxSide) h->n_side = ipc_engine::kMaxSide;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
