@@ -42,6 +42,21 @@ hipError_t launch_se2_block(int nl, int variant, int n, hipStream_t st, const Se
 hipError_t launch_se3_block(int nl, int variant, int n, hipStream_t st, const Se3View& P, const int2* cells,
                             SolveParams prm, CellOut out);
 
+// ---- LDS-pose kernels (SE3, se3_lds_cell.hpp): teams of W = 1 or 4 waves per cell, M poses per lane;
+// capacity 64*W*M.  Policy tokens "wM" (W = 1) and "gM" (W = 4); plan variant id = base + table index.
+struct LdsVariant { int W, M; };
+static const LdsVariant kLdsVariants3[] = { {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 6}, {1, 8},
+                                            {4, 2}, {4, 3}, {4, 4}, {4, 5}, {4, 6}, {4, 7}, {4, 8}, {4, 9}, {4, 10} };
+constexpr int kNumLdsVariants3 = sizeof(kLdsVariants3) / sizeof(kLdsVariants3[0]);
+constexpr int kLdsVariantBase3 = 400;
+#define IPC_SE3_LDS_DECL(WW, MM)                                                                                \
+    hipError_t launch_se3_lds_##WW##_##MM(int nl, int n, hipStream_t st, const Se3View& P, const int2* cells,   \
+                                          SolveParams prm, CellOut out, unsigned* counter, int n_cu);
+IPC_SE3_LDS_DECL(1, 1) IPC_SE3_LDS_DECL(1, 2) IPC_SE3_LDS_DECL(1, 3) IPC_SE3_LDS_DECL(1, 4) IPC_SE3_LDS_DECL(1, 6)
+IPC_SE3_LDS_DECL(1, 8) IPC_SE3_LDS_DECL(4, 2) IPC_SE3_LDS_DECL(4, 3) IPC_SE3_LDS_DECL(4, 4) IPC_SE3_LDS_DECL(4, 5)
+IPC_SE3_LDS_DECL(4, 6) IPC_SE3_LDS_DECL(4, 7) IPC_SE3_LDS_DECL(4, 8) IPC_SE3_LDS_DECL(4, 9) IPC_SE3_LDS_DECL(4, 10)
+#undef IPC_SE3_LDS_DECL
+
 // ---- wave kernels (SE2): one wave per cell, M consecutive poses per lane; capacity 64*M ----
 static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13};
 constexpr int kNumWaveM = sizeof(kWaveM) / sizeof(kWaveM[0]);

@@ -180,6 +180,21 @@ __global__ void k_se3_prep(int n, const double* meas, const double* info, double
     }
 }
 
+// field-major SE3 records -> blocks of 64 edges x kSe3BlkPairs double2 (se3_lds_cell.hpp reads them with
+// one coalesced 16-byte load per lane): pairs 0..5 = Rz, tz; 6..16 = information (+ pad); 17..27 = covariance (+ pad)
+__global__ void k_se3_blocks(int n, const double* rec, int stride, double2* out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double2* o = out + (size_t)(k >> 6) * (kSe3BlkPairs * 64) + (k & 63);
+    auto F = [&](int f) { return rec[(size_t)f * stride + k]; };
+    for (int p = 0; p < 6; ++p) o[p * 64] = make_double2(F(2 * p), F(2 * p + 1));
+    for (int p = 0; p < 11; ++p) {
+        o[(6 + p) * 64] = make_double2(F(G_OM + 2 * p), 2 * p + 1 < 21 ? F(G_OM + 2 * p + 1) : 0.0);
+        o[(17 + p) * 64] = make_double2(F(G_SG + 2 * p), 2 * p + 1 < 21 ? F(G_SG + 2 * p + 1) : 0.0);
+    }
+}
+
 // propagateGuess for SE3: v0 = identity, v[i] = v[i-1] * z[i-1] (Isometry3 product)
 __global__ void k_se3_propagate(int V, const double* rec, int stride, double* pose0)
 {
@@ -351,13 +366,15 @@ static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,
 // engine streams + the caller's stream = the runtime's four hardware queues for SE2; the long SE3
 // launches gain a little from a fourth engine stream
 static const int kDefaultSideStreams2 = 2, kDefaultSideStreams3 = 3;
-static const char* kDefaultPolicy3 = "1x1,1x2,1x3,2x2,2x3,4x2,4x4,8x4,8x5,16x4";
+static const char* kDefaultPolicy3 = "w1,w2,w3,w4,w6,w8,g3,g4,g5,g6,g7,g8,g9,g10,16x4";
+static const char* kBlockPolicy3 = "1x1,1x2,1x3,2x2,2x3,4x2,4x4,8x4,8x5,16x4";   // round-1 block kernels only (IPC_SE3_POLICY=block)
 // SE3 variants for thin bins, by capacity (IPC_SE3_LATENCY_POLICY; "none" disables the switch)
 static const char* kDefaultLatencyPolicy3 = "1x1,2x1,4x1,4x2,4x4,8x4,8x5,16x4";
 static bool make_plan(BinPlan& bp, int dim, std::string& err)
 {
     const char* env = getenv(dim == 2 ? "IPC_SE2_POLICY" : "IPC_SE3_POLICY");
     std::string pol = env && *env ? env : (dim == 2 ? kDefaultPolicy : kDefaultPolicy3);
+    if (dim == 3 && pol == "block") pol = kBlockPolicy3;
     const Variant* table = dim == 2 ? kVariants : kVariants3;
     const int ntable = dim == 2 ? kNumVariants : kNumVariants3;
     std::vector<std::pair<int, int>> items;          // (cap, variant)
@@ -377,6 +394,10 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
         } else if (dim == 2 && sscanf(tok.c_str(), "q%d", &m) == 1) {   // quad kernel, four waves per cell
             w = 4;
             for (int k = 0; k < kNumQuadM; ++k) if (kQuadM[k] == m) v = kQuadVariantBase + m;
+        } else if (dim == 3 && (sscanf(tok.c_str(), "w%d", &m) == 1 || sscanf(tok.c_str(), "g%d", &m) == 1)) {
+            w = tok[0] == 'w' ? 1 : 4;                                     // LDS-pose kernel, teams of 1 / 4 waves
+            for (int k = 0; k < kNumLdsVariants3; ++k)
+                if (kLdsVariants3[k].W == w && kLdsVariants3[k].M == m) v = kLdsVariantBase3 + k;
         } else {
             if (sscanf(tok.c_str(), "%dx%d", &w, &m) != 2) { err = "bad IPC_SE2_POLICY token"; return false; }
             for (int k = 0; k < ntable; ++k) if (table[k].W == w && table[k].M == m) v = k;
@@ -412,6 +433,7 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
             }
             std::sort(lat.begin(), lat.end());
             for (int b = 0; b < bp.caps.n; ++b) {
+                if (bp.variant[b] >= kLdsVariantBase3) continue;             // block variants only
                 const int wt = table[bp.variant[b]].W;
                 for (const auto& lv : lat) {
                     if (lv.first < bp.caps.cap[b]) continue;
@@ -428,6 +450,19 @@ static bool make_plan(BinPlan& bp, int dim, std::string& err)
     return true;
 }
 
+static hipError_t launch_se3_lds(int nl, int idx, int n, hipStream_t st, const Se3View& P, const int2* cells,
+                                 SolveParams prm, CellOut out, unsigned* counter, int n_cu)
+{
+#define IPC_LCASE(i, WW, MM) case i: return launch_se3_lds_##WW##_##MM(nl, n, st, P, cells, prm, out, counter, n_cu);
+    switch (idx) {
+        IPC_LCASE(0, 1, 1) IPC_LCASE(1, 1, 2) IPC_LCASE(2, 1, 3) IPC_LCASE(3, 1, 4) IPC_LCASE(4, 1, 6) IPC_LCASE(5, 1, 8)
+        IPC_LCASE(6, 4, 2) IPC_LCASE(7, 4, 3) IPC_LCASE(8, 4, 4) IPC_LCASE(9, 4, 5) IPC_LCASE(10, 4, 6) IPC_LCASE(11, 4, 7)
+        IPC_LCASE(12, 4, 8) IPC_LCASE(13, 4, 9) IPC_LCASE(14, 4, 10)
+        default: return hipErrorInvalidValue;
+    }
+#undef IPC_LCASE
+}
+
 struct ipc_engine {
     int dim = 2, V = 0, N = 0, device = 0;
     ipc_params_t prm{};
@@ -436,6 +471,7 @@ struct ipc_engine {
     // chain
     double* d_chain = nullptr; int estride = 0;
     double* d_chain_rec = nullptr;                     // record-major copy [E + 64][F_NFIELDS | G_NFIELDS]
+    double2* d_chain_blk = nullptr;                    // SE3: blocked copy [E / 64 + 2][kSe3BlkPairs][64]
     double* d_pose0 = nullptr;
     // candidates
     double* d_cand = nullptr; int cstride = 0;
@@ -542,6 +578,11 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         HIPCHK(hipMemsetAsync(h->d_chain_rec, 0, sizeof(double) * (size_t)G_NFIELDS * (E + 64), h->own_stream));
         hipLaunchKernelGGL(k_records, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, (int)G_NFIELDS, h->d_chain,
                            h->estride, h->d_chain_rec);
+        const size_t nblk = (size_t)(E + 63) / 64 + 2;
+        HIPCHK(hipMalloc(&h->d_chain_blk, sizeof(double2) * nblk * kSe3BlkPairs * 64));
+        HIPCHK(hipMemsetAsync(h->d_chain_blk, 0, sizeof(double2) * nblk * kSe3BlkPairs * 64, h->own_stream));
+        hipLaunchKernelGGL(k_se3_blocks, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, h->d_chain, h->estride,
+                           h->d_chain_blk);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->own_stream));
@@ -565,7 +606,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
     free_candidates(h);
-    hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
+    hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
@@ -687,6 +728,7 @@ static Se3View make_view3(const ipc_engine* h)
     Se3View P;
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
     P.chain_rec = h->d_chain_rec;
+    P.chain_blk = h->d_chain_blk;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     return P;
 }
@@ -773,6 +815,9 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
                         ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
                                           h->d_wave_ctr + s, h->n_cu)
                         : launch_se2_block(nl, var, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out);
+            else if (var >= kLdsVariantBase3)
+                e = launch_se3_lds(nl, var - kLdsVariantBase3, (int)counts[s], ls, P3, h->d_cells + offsets[s], sp, out,
+                                   h->d_wave_ctr + s, h->n_cu);
             else
                 e = launch_se3_block(nl, var, (int)counts[s], ls, P3, h->d_cells + offsets[s], sp, out);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));

@@ -26,10 +26,14 @@ namespace ipc {
 // triangle (21, row order, already scaled by s for odometry), Sigma = Omega^-1 upper (21)
 enum Se3Field { G_RZ = 0, G_TZ = 9, G_OM = 12, G_SG = 33, G_NFIELDS = 54 };
 
+// blocked chain records: pairs 0..5 = Rz (9) + tz (3), 6..16 = information (21 + pad), 17..27 = covariance (21 + pad)
+constexpr int kSe3BlkPairs = 28;
+
 struct Se3View {
     const double* chain;      // [G_NFIELDS][estride]
     int estride;
     const double* chain_rec;  // the same values record-major: [edge][G_NFIELDS]
+    const double2* chain_blk; // the same values in blocks of 64 edges: [block][kSe3BlkPairs][64] double2 (se3_lds_cell.hpp)
     const double* pose0;      // [12][V] open-loop poses: R row-major (9), t (3)
     int V;
     const double* cand;       // [G_NFIELDS][cstride]
