@@ -756,6 +756,58 @@ double oracle_pair_cell(int dim, const double *odom_meas, const double *odom_inf
                              lid, lm, li, slow_iter, NULL, NULL, stats);
 }
 
+/* Batch of pair cells over a static partition of the list across POSIX threads (thread t takes cells
+ * t, t + T, t + 2T, ...): the all-core CPU baseline SURVEY.md 8(d) asks for (the reference itself is
+ * single-threaded; its only concurrency is independent processes, bash/ipc_experiments_2D.sh:34).
+ * max_chi2_out / iterations_out have n entries.  Returns the number of threads actually started. */
+#include <pthread.h>
+typedef struct {
+    int dim; const double *odom_meas, *odom_info; double s_factor; const double *poses; const int *ids;
+    const double *meas, *info; int fast_iter, slow_iter; int n; const int *ci, *cj; double *mx; int *its;
+    int t, T;
+} mt_job_t;
+static void *mt_worker(void *arg)
+{
+    mt_job_t *q = (mt_job_t *)arg;
+    for (int k = q->t; k < q->n; k += q->T) {
+        int solved;
+        oracle_stats_t st;
+        memset(&st, 0, sizeof st);
+        double c = oracle_pair_cell(q->dim, q->odom_meas, q->odom_info, q->s_factor, q->poses, q->ids, q->meas,
+                                    q->info, q->ci[k], q->cj[k], q->fast_iter, q->slow_iter, &solved, &st);
+        q->mx[k] = solved ? c : NAN;
+        if (q->its) q->its[k] = st.iterations;
+    }
+    return NULL;
+}
+int oracle_pair_cells_mt(int dim, const double *odom_meas, const double *odom_info, double s_factor,
+                         const double *poses, const int *ids, const double *meas, const double *info,
+                         int fast_iter, int slow_iter, int n, const int *ci, const int *cj, int nthreads,
+                         double *max_chi2_out, int *iterations_out)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    mt_job_t *jobs = (mt_job_t *)malloc(sizeof(mt_job_t) * (size_t)nthreads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        mt_job_t j = { dim, odom_meas, odom_info, s_factor, poses, ids, meas, info, fast_iter, slow_iter, n, ci, cj,
+                       max_chi2_out, iterations_out, t, nthreads };
+        jobs[t] = j;
+    }
+    for (int t = 1; t < nthreads; ++t)
+        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t]) == 0) ++started;
+        else { jobs[t].T = 0; }
+    /* a thread that could not be created: its share is done here after ours */
+    mt_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; ++t) {
+        if (jobs[t].T) pthread_join(th[t], NULL);
+        else { jobs[t].T = nthreads; mt_worker(&jobs[t]); }
+    }
+    free(jobs); free(th);
+    return started + 1;
+}
+
 /* Full matrix over candidates [0,N): maxchi2 (N*N doubles, symmetric, NaN where the cell is
  * not solved), okmat (N*N bytes).  rows_begin/rows_end/row_stride restrict the owner rows
  * (cells (i,j), i<=j, with i in the row set) -- used for shard tests; other cells untouched. */

@@ -172,6 +172,22 @@ def pair_cell(dim, odom_meas, odom_info, s_factor, poses, ids, meas, info, i, j,
     return bool(solved.value), mx, st.iterations
 
 
+def pair_cells_mt(dim, odom_meas, odom_info, s_factor, poses, ids, meas, info, ci, cj, fast_iter, slow_iter,
+                  nthreads):
+    """Batch of pair cells over `nthreads` POSIX threads (static partition).  Returns
+    (max_chi2 [n] with NaN where the pair does not overlap, iterations [n], threads used)."""
+    odom_meas, odom_info, poses = _d(odom_meas), _d(odom_info), _d(poses)
+    ids, meas, info = _i(ids), _d(meas), _d(info)
+    ci, cj = _i(ci), _i(cj)
+    n = ci.shape[0]
+    mx = np.zeros(n)
+    its = np.zeros(n, dtype=np.int32)
+    used = lib().oracle_pair_cells_mt(dim, _p(odom_meas), _p(odom_info), C.c_double(s_factor), _p(poses), _p(ids),
+                                      _p(meas), _p(info), int(fast_iter), int(slow_iter), n, _p(ci), _p(cj),
+                                      int(nthreads), _p(mx), _p(its))
+    return mx, its, used
+
+
 def consistency_matrix(dim, odom_meas, odom_info, s_factor, ids, meas, info, fast_th, fast_iter,
                        slow_th, slow_iter):
     """Returns (okmat uint8 N x N, maxchi2 N x N with NaN on non-overlapping cells)."""
