@@ -33,11 +33,13 @@ F_ITER = {1: 272.0, 2: 447.0}    # b, alpha, capacitance reduction, step, scans 
 F_EVAL = 80.0                    # sincos + residual + chi2 -- per error evaluation
 F_TRY = 70.0                     # step candidate, linear gain, update -- per evaluated trial
 B_ODOM = 72.0                    # bytes of one odometry record (3 + 6 doubles), SURVEY.md 8d
-# SE3 kernel (6x6 blocks): same structure, DESIGN.md
-F_ITER3 = {1: 3000.0, 2: 5200.0}
-F_EVAL3 = 270.0
-F_TRY3 = 150.0
+# SE3 (6x6 blocks): SURVEY.md 8(d)'s figure F_6 = 3000 flops per pose and outer iteration, trial evaluations
+# included (the executed count from the SQ_INSTS_VALU_*_F64 counters is reported next to it)
+F_ITER3 = {1: 3000.0, 2: 3000.0}
+F_EVAL3 = 0.0
+F_TRY3 = 0.0
 B_ODOM3 = 224.0                  # 7 + 21 doubles
+F_SURVEY = {2: 450.0, 3: 3000.0}  # SURVEY.md 8(d) placeholders: flops per pose and outer iteration
 
 
 def build_workload(name):
@@ -91,35 +93,115 @@ def build_workload(name):
     return g, cfg, desc
 
 
-def cpu_baseline(g, cfg, cells, budget_s):
-    """Times the CPU oracle (1 thread) on a bounded, L-stratified sample of the same cells."""
-    from oracle import oracle as O
-    poses = O.propagate(g.dim, g.odom_meas)
+def _stratified_sample(cells, n_target, seed=0):
+    """Indices of an L-stratified sample of the solved cells, in random order."""
     L = (cells["hi"] - cells["lo"]).astype(np.int64)
     order = np.argsort(L, kind="stable")
-    n_target = 4096
     pick = order[np.linspace(0, len(order) - 1, min(n_target, len(order))).astype(np.int64)]
-    rng = np.random.default_rng(0)
-    rng.shuffle(pick)                      # any prefix of `pick` is an unbiased stratified sample
+    rng = np.random.default_rng(seed)
+    rng.shuffle(pick)                      # any prefix is an unbiased stratified sample; shards are balanced
+    return pick
+
+
+def cpu_baseline(g, cfg, cells, budget_s):
+    """The CPU oracle (plain-C restatement of the reference path, oracle/) on the GPU box's host cores,
+    SURVEY.md 8(d): an L-stratified sample of the same solved cells; all-core leg = static partition over
+    POSIX threads, median of 5; 1-thread leg (the reference is single-threaded) on a prefix of the sample."""
+    from oracle import oracle as O
+    poses = O.propagate(g.dim, g.odom_meas)
+    cores = os.cpu_count() or 1
+    pick = _stratified_sample(cells, 2048)
+
+    def run(idx, threads):
+        t0 = time.perf_counter()
+        mx, its, used = O.pair_cells_mt(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids, g.loop_meas,
+                                        g.loop_info, cells["i"][idx], cells["j"][idx], cfg.fast_reject_iter_base,
+                                        cfg.slow_reject_iter_base, threads)
+        return time.perf_counter() - t0, mx, used
+
+    # size the legs to the budget from a short 1-thread probe
+    n_probe, t_probe = 0, 0.0
+    while n_probe < min(32, len(pick)) and t_probe < 1.5:
+        dtp, _, _ = run(pick[n_probe:n_probe + 2], 1)
+        t_probe += dtp
+        n_probe += 2
+    rate1 = n_probe / max(t_probe, 1e-9)
+    n1 = int(max(n_probe, min(len(pick), rate1 * budget_s * 0.45)))
+    n_all = int(max(n_probe, min(len(pick), rate1 * min(cores, 64) * 0.6 * budget_s * 0.55 / 5)))
+    t1, mx1, _ = run(pick[:n1], 1)
+    reps = []
+    for _ in range(5):
+        ta, mxa, used = run(pick[:n_all], cores)
+        reps.append(ta)
+    t_all = float(np.median(reps))
+    th = np.where(cells["i"] == cells["j"], cfg.fast_reject_th, cfg.slow_reject_th)
+    idx = pick[:max(n1, n_all)]
+    mx = mxa if n_all >= n1 else mx1
+    mism = int(((~(mx > th[idx])) != (~(cells["max_chi2"][idx] > th[idx]))).sum())
+    rel = np.abs(mx - cells["max_chi2"][idx]) / np.maximum(np.abs(mx), 1e-300)
+    one = dict(value=n1 / t1, unit="candidate-pairs/s", cores=1, kind="port",
+               sample="%d solved cells (prefix of the all-core sample), %.1f s, one run" % (n1, t1))
+    return dict(value=n_all / t_all, unit="candidate-pairs/s", cores=used, kind="port",
+                sample="%d solved cells, L-stratified over the chain-length order of the same workload, static "
+                       "partition over %d POSIX threads (host reports %d cores), median of 5 runs (%.2f s each); "
+                       "the CPU side is this repo's plain-C restatement (oracle/), not g2o -- the reference cannot be "
+                       "built here; non-overlapping pairs are free on both sides and excluded from this rate" % (
+                           n_all, used, cores, t_all),
+                single_thread=one,
+                decisions_differing_from_gpu=mism,
+                max_rel_chi2_diff_vs_gpu=float(np.nanmax(rel)) if len(rel) else 0.0)
+
+
+def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s):
+    """The reference's own metric (src/simulation.cpp:36-44,87): mean wall time per agreementCheck in the
+    faithful incremental mode, as candidates/s -- GPU (ipc_agreement_check) and CPU oracle on the same prefix
+    of the candidate order."""
+    from oracle import oracle as O
+    order = eng.candidate_order()
+    n_gpu = min(gpu_candidates, len(order))
+    eng.reset()
+    eng.synchronize()
     t0 = time.perf_counter()
-    done = 0
-    mism = 0
-    for idx in pick:
-        c = cells[idx]
-        _, mx, _ = O.pair_cell(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids, g.loop_meas,
-                               g.loop_info, int(c["i"]), int(c["j"]), cfg.fast_reject_iter_base,
-                               cfg.slow_reject_iter_base)
-        th = cfg.fast_reject_th if c["i"] == c["j"] else cfg.slow_reject_th
-        mism += int((not (mx > th)) != (not (c["max_chi2"] > th)))
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
+    acc_gpu = []
+    for k in order[:n_gpu]:
+        acc_gpu.append(eng.agreementCheck(int(k)))
+    eng.synchronize()
+    t_gpu = time.perf_counter() - t0
+    cpu = O.IncrementalIPC(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                           cfg.slow_reject_th, cfg.slow_reject_iter_base, g.loop_ids, g.loop_meas, g.loop_info)
+    t0 = time.perf_counter()
+    acc_cpu = []
+    for k in order[:n_gpu]:
+        ok, _ = cpu.agreement_check(int(k))
+        acc_cpu.append(ok)
+        if time.perf_counter() - t0 > cpu_budget_s:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="candidate-pairs/s", cores=1, kind="port",
-                sample="%d solved cells, uniformly drawn over the chain-length order of the same workload, "
-                       "%.1f s of CPU oracle (1 thread); non-overlapping pairs are free on both sides and "
-                       "are excluded from this rate" % (done, dt),
-                decisions_differing_from_gpu=mism)
+    t_cpu = time.perf_counter() - t0
+    n_cpu = len(acc_cpu)
+    return dict(unit="candidates/s", gpu=n_gpu / t_gpu, gpu_candidates=n_gpu, gpu_avg_time_x_test_s=t_gpu / n_gpu,
+                cpu_1t=n_cpu / t_cpu, cpu_candidates=n_cpu, cpu_avg_time_x_test_s=t_cpu / n_cpu,
+                decisions_differing_on_common_prefix=int(sum(a != b for a, b in zip(acc_gpu[:n_cpu], acc_cpu))),
+                note="reference metric 'Avg Time x test' (src/simulation.cpp:87) as a rate; the same prefix of the "
+                     "cmpTime candidate order on both sides, CPU = oracle IncrementalIPC (1 thread)")
+
+
+def executed_flops(workload, dim):
+    """Executed FP64 flops of the cell-solver kernels of ONE solve of this workload, from the committed rocprofv3
+    PMC pass profiles/r2_<workload>_pmc_sq.csv (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 are wave-level
+    instruction counts: x 64 lanes, FMA = 2 flops).  None when no such file is committed."""
+    path = os.path.join(ROOT, "profiles", "r2_%s_pmc_sq.csv" % workload.lower())
+    if not os.path.exists(path):
+        return None
+    import csv
+    c = {}
+    for r in csv.DictReader(open(path)):
+        if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_group_kernel", "_lds_kernel")):
+            c[r["counter"]] = c.get(r["counter"], 0.0) + float(r["sum_value"])
+    if "SQ_INSTS_VALU_FMA_F64" not in c:
+        return None
+    return dict(flops=64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                              + c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)),
+                mfma_mops_f64=c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), source=os.path.relpath(path, ROOT))
 
 
 def main():
@@ -128,16 +210,27 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--incremental-candidates", type=int, default=-1,
+                    help="candidates of the faithful incremental mode to time (reference metric); -1: 128 for SE2 "
+                         "workloads at 1 GPU, 0 otherwise")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: re-launch as N ranks (one per GPU) under torch.distributed.run
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     from ipc_amd.consensus import IPC
     from ipc_amd.dist import EngineBackend, ShardedMatrix
@@ -196,23 +289,31 @@ def main():
         import csv
         f = w = 0.0
         for r in csv.DictReader(open(pmc_csv)):
-            if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_pair_kernel", "_group_kernel")):
+            if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_pair_kernel", "_group_kernel", "_lds_kernel")):
                 if r["counter"] == "FETCH_SIZE":
                     f += float(r["sum_value"])
                 elif r["counter"] == "WRITE_SIZE":
                     w += float(r["sum_value"])
         traffic = (2.0 * f + w) * 1024.0
     achieved_tflops = flops / (sms * 1e-3) / 1e12
+    pose_iters = float((L * cells["iterations"]).sum())
+    ex = executed_flops(args.workload, g.dim) if world == 1 else None
     roofline = {"bound": "mfma", "compute_unit": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
+                "frac_survey_model": round(pose_iters * F_SURVEY[g.dim] / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
+                "executed_fp64_flops_per_step": ex["flops"] if ex else None,
+                "frac_executed": round(ex["flops"] / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if ex else None,
+                "executed_source": (ex["source"] + " (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 of one solve of this workload; "
+                                    "SQ_INSTS_VALU_MFMA_MOPS_F64 = %s)" % ex["mfma_mops_f64"]) if ex else None,
                 "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
                                 "L2-resident" % args.workload,
-                "kernel": "se%d_cells_kernel<W,M,NL>%s (%d launches per step, one per chain-length bin and loop count)" % (
-                    g.dim, " + se2_wave_kernel<M,NL,STAGED> + se2_group_kernel<W,M,NL,STAGED>" if g.dim == 2 else "", launches),
+                "kernel": "%s (%d launches per step, one per chain-length bin and loop count)" % (
+                    "se2_wave_kernel<M,NL,STAGED> + se2_group_kernel<W,M,NL,STAGED> + se2_cells_kernel<W,M,NL>" if g.dim == 2
+                    else "se3_lds_kernel<W,M,NL> (+ se3_cells_kernel<W,M,NL> beyond 2560 poses)", launches),
                 "kernel_ms_per_step": round(sms, 4),
                 "algorithmic_flops_per_step": flops,
-                "pose_iterations_per_step": float((L * cells["iterations"]).sum()),
+                "pose_iterations_per_step": pose_iters,
                 "note": "compute-bound: priced against the dense FP64 MFMA peak, which on MI355X equals the FP64 "
                         "vector-ALU peak (78.6 TFLOP/s); the work has no MFMA-shaped products, its instructions "
                         "issue on the FP64 VALU; the HBM roof is far away, see roofline_hbm"}
@@ -244,11 +345,18 @@ def main():
     bits, acc = sm.result()
     out["accepted"] = int(acc.sum())
     out["solved_cells_rank0"] = int(len(cells))
+    out["solved_cells_per_s"] = len(cells) * world * 1.0 / (ms_per_step * 1e-3) if world == 1 else None
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, cfg, cells, args.cpu_seconds)
-        gpu_solved_rate = len(cells) * 1.0 / (sms * 1e-3)
+        gpu_solved_rate = len(cells) * 1.0 / (ms_per_step * 1e-3)
         out["cpu_baseline"]["gpu_solved_cells_per_s"] = gpu_solved_rate
-        out["cpu_baseline"]["speedup_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["value"]
+        out["cpu_baseline"]["gpu_over_cpu_all_cores_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["value"]
+        out["cpu_baseline"]["gpu_over_cpu_1_thread_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["single_thread"]["value"]
+        n_inc = args.incremental_candidates
+        if n_inc < 0:
+            n_inc = 128 if g.dim == 2 else 0
+        if n_inc > 0:
+            out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

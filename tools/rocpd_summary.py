@@ -23,7 +23,7 @@ def main(path):
     # under the next bins), so their durations do not add up to wall time.  The figure that
     # corresponds to bench.py's HIP-event time is the busy time of their union, per step (a step
     # starts with two k_plan launches).
-    iv = cur.execute("select start, end from kernels where name like '%_cells_kernel%' or name like '%_wave_kernel%' "
+    iv = cur.execute("select start, end from kernels where name like '%_cells_kernel%' or name like '%_lds_kernel%' or name like '%_wave_kernel%' "
                      "or name like '%_group_kernel%' order by start").fetchall()
     steps = cur.execute("select count(*) from kernels where name like 'k_plan%'").fetchone()[0] // 2
     busy, lo, hi = 0, None, None
