@@ -1,0 +1,198 @@
+// consensus_amd.hpp -- drop-in for the reference's include/ipc/consensus.hpp (class surface of
+// reference include/ipc/consensus.hpp:5-33, behaviour of src/consensus.cpp) on top of libipc_amd.so.
+//
+// Put this header (and include/ipc_amd.h) on the reference's include path, include it instead of
+// "ipc/consensus.hpp", drop src/consensus.cpp from the build and link -lipc_amd: ipc_tester_2D/3D and
+// src/simulation.cpp compile unchanged -- `IPC<EDGE, VERTEX> ipc(problem, cfg); ipc.agreementCheck(e);
+// ipc.getMaxConsensusSet()` keep their meaning.  The g2o optimizer still owns the graph; the engine
+// keeps its own copy of the odometry chain, the candidate edges it has seen and the pose state on
+// the GPU.
+//
+// What the reference header pulls in is expected from "ipc/utils.hpp" (Config, getProblemOdom,
+// cmpEdgesID; reference include/ipc/utils.hpp:22-38,98-121) -- unchanged reference code.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <type_traits>
+#include <unordered_map>
+#include <vector>
+
+#include "ipc/utils.hpp"
+#include "ipc_amd.h"
+
+namespace ipc_amd_adapter {
+
+// the numbers of the edge's line in the .g2o file: SE2 "x y theta", SE3 "x y z qx qy qz qw"
+template <class EDGE>
+inline void pack_measurement(const EDGE& e, std::vector<double>& out, std::integral_constant<int, 3>)
+{
+    const auto v = e.measurement().toVector();                     // g2o::SE2::toVector
+    out.push_back(v[0]); out.push_back(v[1]); out.push_back(v[2]);
+}
+template <class EDGE>
+inline void pack_measurement(const EDGE& e, std::vector<double>& out, std::integral_constant<int, 6>)
+{
+    const auto v = g2o::internal::toVectorQT(e.measurement());     // what EdgeSE3::write stores
+    for (int k = 0; k < 7; ++k) out.push_back(v[k]);
+}
+// upper triangle of the information matrix in row order (the file layout, reference src/utils.cpp:114)
+template <class EDGE>
+inline void pack_information_upper(const EDGE& e, std::vector<double>& out)
+{
+    constexpr int D = EDGE::Dimension;
+    const auto& I = e.information();
+    for (int i = 0; i < D; ++i)
+        for (int j = i; j < D; ++j) out.push_back(I(i, j));
+}
+
+}  // namespace ipc_amd_adapter
+
+template <class EDGE, class VERTEX>
+class IPC {
+public:
+    using Dim = std::integral_constant<int, EDGE::Dimension>;      // 3: SE2, 6: SE3
+
+    // reference src/consensus.cpp:9-33
+    IPC(g2o::SparseOptimizer& open_loop_problem, const Config& cfg, int device = 0) : _problem(&open_loop_problem)
+    {
+        std::vector<EDGE*> odom;
+        getProblemOdom<EDGE>(open_loop_problem, odom);             // src/utils.cpp:218-231
+        std::sort(odom.begin(), odom.end(), cmpEdgesID);           // src/consensus.cpp:15
+        std::vector<double> meas, info;
+        for (EDGE* e : odom) {
+            ipc_amd_adapter::pack_measurement(*e, meas, Dim{});
+            ipc_amd_adapter::pack_information_upper(*e, info);
+        }
+        const ipc_params_t p{cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th,
+                             cfg.slow_reject_iter_base, cfg.s_factor};
+        chk(ipc_create(EDGE::Dimension == 3 ? 2 : 3, (int)odom.size() + 1, meas.data(), info.data(), &p, device, &_h));
+    }
+    // reference src/consensus.cpp:35-40 (clears the caller's graph, as the reference does)
+    ~IPC()
+    {
+        ipc_destroy(_h);
+        _problem->clear();
+    }
+    IPC(const IPC&) = delete;
+    IPC& operator=(const IPC&) = delete;
+
+    // The candidate list of the run (reference src/simulation.cpp:24-26: the harness's `loops`, any
+    // order): uploads it once.  Optional -- agreementCheck() registers unseen edges by itself, at the
+    // price of a re-upload (which resets the engine's consensus state, so it replays the accepted
+    // edges; call this first to avoid that).
+    void setCandidates(const std::vector<EDGE*>& candidates)
+    {
+        _cands = candidates;
+        _index_of.clear();
+        for (size_t k = 0; k < _cands.size(); ++k) _index_of[_cands[k]] = (int)k;
+        upload();
+    }
+
+    // reference src/consensus.cpp:43-75: cluster, thresholds, solve from the current estimates,
+    // keep / restore, propagateCurrentGuess -- on the GPU
+    bool agreementCheck(EDGE* loop_candidate)
+    {
+        const int k = index_of(loop_candidate);
+        int ok = 0;
+        chk(ipc_agreement_check(_h, k, &ok, nullptr));
+        if (ok) _max_consensus_set.push_back(loop_candidate);
+        return ok != 0;
+    }
+
+    // Batched re-formulation (consistency matrix + set-max) of the harness
+    // loop src/simulation.cpp:34-47 over `candidates`: per candidate, whether it is in the set.
+    std::vector<char> agreementCheckAll(const std::vector<EDGE*>& candidates)
+    {
+        setCandidates(candidates);
+        std::vector<uint8_t> acc(candidates.size());
+        std::vector<int> order(candidates.size());
+        if (!candidates.empty()) {
+            chk(ipc_run(_h, nullptr, acc.data()));
+            chk(ipc_candidate_order(_h, order.data()));
+        }
+        _max_consensus_set.clear();
+        for (int k : order)
+            if (acc[k]) _max_consensus_set.push_back(candidates[k]);
+        return std::vector<char>(acc.begin(), acc.end());
+    }
+
+    // reference src/consensus.cpp:77-96
+    bool removeEdgeFromCnS(EDGE* edge_to_remove)
+    {
+        int removed = 0;
+        chk(ipc_remove_from_consensus(_h, index_of(edge_to_remove), &removed));
+        if (removed) refresh_set();
+        return removed != 0;
+    }
+    // reference src/consensus.cpp:98-119
+    void addEdgeToCnS(EDGE* edge_to_add)
+    {
+        chk(ipc_add_to_consensus(_h, index_of(edge_to_add)));
+        refresh_set();
+    }
+    // reference include/ipc/consensus.hpp:16
+    const std::vector<EDGE*>& getMaxConsensusSet() const { return _max_consensus_set; }
+
+    // The g2o vertex estimates are the reference's state (IPC::agreementCheck mutates them); the
+    // engine keeps that state on the GPU.  Callers that read the estimates afterwards copy them back:
+    // SE2 [V][3] (x y theta), SE3 [V][12] (R row-major, t).
+    void currentPoses(std::vector<double>& out) const
+    {
+        out.resize((size_t)numVertices() * (EDGE::Dimension == 3 ? 3 : 12));
+        chk(ipc_current_poses(_h, out.data()));
+    }
+    int numVertices() const { return (int)_problem->vertices().size(); }
+
+private:
+    static void chk(int rc)
+    {
+        if (rc) throw std::runtime_error(ipc_last_error());
+    }
+    void upload()
+    {
+        std::vector<int> ids;
+        std::vector<double> meas, info;
+        for (EDGE* e : _cands) {
+            ids.push_back(e->vertices()[0]->id());
+            ids.push_back(e->vertices()[1]->id());
+            ipc_amd_adapter::pack_measurement(*e, meas, Dim{});
+            ipc_amd_adapter::pack_information_upper(*e, info);
+        }
+        chk(ipc_set_candidates(_h, (int)_cands.size(), ids.data(), meas.data(), info.data()));
+    }
+    int index_of(EDGE* e)
+    {
+        auto it = _index_of.find(e);
+        if (it != _index_of.end()) return it->second;
+        // an edge the engine has not seen: append, re-upload, replay the accepted edges so that the
+        // pose state and the consensus set are what they were (same order => same state)
+        _cands.push_back(e);
+        const int k = (int)_cands.size() - 1;
+        _index_of[e] = k;
+        upload();
+        const std::vector<EDGE*> accepted = _max_consensus_set;
+        _max_consensus_set.clear();
+        for (EDGE* a : accepted) {
+            int ok = 0;
+            chk(ipc_agreement_check(_h, _index_of.at(a), &ok, nullptr));
+            if (ok) _max_consensus_set.push_back(a);
+        }
+        return k;
+    }
+    void refresh_set()
+    {
+        int n = 0;
+        chk(ipc_consensus_size(_h, &n));
+        std::vector<int> idx((size_t)std::max(n, 1));
+        chk(ipc_consensus_set(_h, idx.data()));
+        _max_consensus_set.clear();
+        for (int q = 0; q < n; ++q) _max_consensus_set.push_back(_cands[(size_t)idx[q]]);
+    }
+
+    g2o::SparseOptimizer* _problem;
+    ipc_engine_t* _h = nullptr;
+    std::vector<EDGE*> _cands;
+    std::unordered_map<EDGE*, int> _index_of;
+    std::vector<EDGE*> _max_consensus_set;
+};

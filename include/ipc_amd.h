@@ -38,7 +38,8 @@ typedef enum {
     IPC_ERR_ARG = -1,        /* bad argument / out-of-contract graph        */
     IPC_ERR_HIP = -2,        /* HIP runtime failure (message has the detail) */
     IPC_ERR_STATE = -3,      /* call order (e.g. no candidates set)          */
-    IPC_ERR_LIMIT = -4       /* chain longer than the largest kernel variant */
+    IPC_ERR_LIMIT = -4       /* a size the engine cannot hold (ipc_set_max: N beyond the LDS-resident mask);
+                                chains of any length are solved -- see ipc_solve_rows */
 } ipc_status;
 
 /* The knobs the path reads: struct Config fields used by IPC::IPC
@@ -101,6 +102,25 @@ int ipc_rows_per_rank(int n, int world);
  * consistent.  Non-overlapping pairs are not solved (their bit stays 0; see
  * ipc_assemble_matrix). */
 int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream);
+/* Stream contract of ipc_solve_rows: the call enqueues on `stream` and on streams of the engine that
+ * fork from / join back into it, and it blocks the HOST once (the cell count comes back from the
+ * planning pass; buffers grow with hipMalloc on the first call or when N grows).  Cells whose chain
+ * is longer than the largest cell kernel (SE3: 4096 poses, SE2: 16384 with the default policies) are
+ * solved one at a time by the cluster solver of ipc_agreement_check -- correct for any length, host
+ * driven and slow (reference cfg/3D/GRID_params.yaml: 8000 poses); ipc_solve_report() counts them. */
+
+/* Counts over the cells of the last ipc_solve_rows() (blocks until the device is idle). */
+typedef struct {
+    int cells;               /* solved cells                                                   */
+    int long_cells;          /* of those, solved by the cluster-solver fallback                */
+    int failed_cells;        /* linear solve hit a non-positive pivot (flags & 2): the cell's
+                                chi2 is that of the last good state, g2o would have retried with
+                                Levenberg damping -- treat a non-zero count as a warning       */
+    int capped_cells;        /* ran to the iteration cap without the dog-leg terminating       */
+    int nan_cells;           /* max chi2 is NaN (counts as "agrees", like chi2 > th does in
+                                the reference, src/consensus_utils.cpp:18)                     */
+} ipc_solve_report_t;
+int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out);
 
 /* Build the full symmetric N x N bit matrix (row-major, ceil(N/64) words per row) from the
  * all-gathered shards d_gathered[world][rows_per_rank][words]:  C[i][j] = solved bit when the

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libipc_amd.so")
 SYMBOLS = [
     "ipc_last_error", "ipc_create", "ipc_destroy", "ipc_set_candidates", "ipc_candidate_order",
     "ipc_initial_poses", "ipc_rows_per_rank", "ipc_solve_rows", "ipc_assemble_matrix", "ipc_set_max",
-    "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solver_time_ms", "ipc_synchronize",
+    "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
 ]
@@ -38,6 +38,11 @@ class CheckInfo(C.Structure):
     _fields_ = [("lo", C.c_int), ("hi", C.c_int), ("n_cluster_loops", C.c_int), ("iterations", C.c_int),
                 ("tries", C.c_int), ("flags", C.c_int), ("max_chi2", C.c_double), ("chi2_total", C.c_double),
                 ("chi2_initial", C.c_double)]
+
+
+class SolveReport(C.Structure):
+    _fields_ = [("cells", C.c_int), ("long_cells", C.c_int), ("failed_cells", C.c_int), ("capped_cells", C.c_int),
+                ("nan_cells", C.c_int)]
 
 
 CELL_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("max_chi2", "<f8"),
@@ -81,6 +86,7 @@ def load():
     lib.ipc_run.argtypes = [vp, vp, vp]
     lib.ipc_cell_count.argtypes = [vp, C.POINTER(ip)]
     lib.ipc_cell_info.argtypes = [vp, vp, ip]
+    lib.ipc_solve_report.argtypes = [vp, C.POINTER(SolveReport)]
     lib.ipc_solver_time_ms.argtypes = [vp, C.POINTER(dp), C.POINTER(ip)]
     lib.ipc_synchronize.argtypes = [vp]
     lib.ipc_incremental_reset.argtypes = [vp]

@@ -163,6 +163,12 @@ class IPC:
         capi.check(self.lib.ipc_cell_info(self.h, _p(out), n.value))
         return out[:n.value]
 
+    def solve_report(self):
+        """Counts over the cells of the last solve: dict(cells, long_cells, failed_cells, capped_cells, nan_cells)."""
+        r = capi.SolveReport()
+        capi.check(self.lib.ipc_solve_report(self.h, C.byref(r)))
+        return {k: getattr(r, k) for k, _ in capi.SolveReport._fields_}
+
     def solver_time_ms(self):
         ms, nl = C.c_double(0), C.c_int(0)
         capi.check(self.lib.ipc_solver_time_ms(self.h, C.byref(ms), C.byref(nl)))

@@ -222,8 +222,8 @@ __global__ void k_se3_propagate(int V, const double* rec, int stride, double* po
 __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world, BinCaps bc,
                        unsigned* counters, const unsigned* offsets, int2* cells, int fill)
 {
-    const int i = blockIdx.y;
-    if (i % world != rank) return;
+    for (int i = blockIdx.y; i < N; i += gridDim.y) {
+    if (i % world != rank) continue;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     int slot = -1;
     if (j < N && j >= i) {
@@ -252,6 +252,7 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
         }
         todo &= ~same;
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,8 +273,8 @@ __global__ void k_assemble(int N, int words, int world, int rpr, const int* lo, 
                            const unsigned long long* gathered, unsigned long long* bits)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
     if (w >= words) return;
+    for (int i = blockIdx.y; i < N; i += gridDim.y) {
     auto U = [&](int a, int c) -> unsigned {        // a <= c
         const unsigned long long word = gathered[((size_t)(a % world) * rpr + a / world) * words + (c >> 6)];
         return (unsigned)((word >> (c & 63)) & 1ull);
@@ -291,6 +292,7 @@ __global__ void k_assemble(int N, int words, int world, int rpr, const int* lo, 
         out |= (unsigned long long)bit << b;
     }
     bits[(size_t)i * words + w] = out;
+    }
 }
 
 // Greedy set-max: candidates in processing order, 16 per round (one wave each).
@@ -484,7 +486,7 @@ struct ipc_engine {
     int n_cu = 256;
     int2* d_cells = nullptr; size_t cells_cap = 0;
     double *d_chi = nullptr, *d_chitot = nullptr; int4* d_meta = nullptr;
-    int last_cells = 0;
+    int last_cells = 0, last_long_cells = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false; int last_launches = 0;
     // side streams: the bin launches of one solve are spread over them so that the tail of one
     // launch (a few cells that run to the iteration cap) overlaps the next bins
@@ -640,7 +642,6 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
-    const int maxL = h->plan.caps.cap[h->plan.caps.n - 1];
     for (int k = 0; k < n; ++k) {
         from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
         if (from[k] < 0 || to[k] < 0 || from[k] >= h->V || to[k] >= h->V)
@@ -650,7 +651,6 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
                         "reference src/utils.cpp:184)", k, from[k], to[k]);
         h->h_lo[k] = std::min(from[k], to[k]); h->h_hi[k] = std::max(from[k], to[k]);
     }
-    (void)maxL;
     // cmpTime order (src/utils.cpp:379-390) with the (max id, index) tie-break
     h->order.resize(n);
     std::iota(h->order.begin(), h->order.end(), 0);
@@ -733,6 +733,52 @@ static Se3View make_view3(const ipc_engine* h)
     return P;
 }
 
+static int ensure_incremental(ipc_engine* h, const char* who);
+static PoseArr pose_arr(double* base, int V);
+
+// Cells beyond the capacity of every cell kernel (SE3 > 4096 poses, SE2 > 16384 with the default
+// policies): the same check (reference src/consensus_utils.cpp:7-22 on chain lo..hi + the one or two
+// loop edges, open-loop start, fast / slow iteration base) through the cluster solver, whose state
+// lives in HBM.  Host driven and serial -- meant for the handful of full-span loops of a long
+// trajectory (reference cfg/3D/GRID_params.yaml), not as a fast path.
+static int solve_long_cells(ipc_engine* h, hipStream_t st, int nb, const unsigned* counts, const unsigned* offsets)
+{
+    if (int rc = ensure_incremental(h, "ipc_solve_rows")) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    for (int nl = 1; nl <= 2; ++nl) {
+        const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + nb;
+        const unsigned n = counts[s];
+        if (!n) continue;
+        std::vector<int2> cells(n);
+        HIPCHK(hipMemcpy(cells.data(), h->d_cells + offsets[s], sizeof(int2) * n, hipMemcpyDeviceToHost));
+        std::vector<double> chi(n), tot(n);
+        std::vector<int4> meta(n);
+        for (unsigned c = 0; c < n; ++c) {
+            const int i = cells[c].x, j = cells[c].y;
+            const int lo = std::min(h->h_lo[i], h->h_lo[j]), hi = std::max(h->h_hi[i], h->h_hi[j]);
+            std::vector<int> members{i};
+            if (nl == 2) members.push_back(j);
+            int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
+            if ((hi - lo) + nl > 100) iters *= 5;                              // consensus_utils.cpp:12-13
+            ClusterOut o;
+            if (h->dim == 3)
+                HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_open, h->V,
+                                          lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
+            else
+                HIPCHK(h->cluster->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride,
+                                         pose_arr(h->d_open, h->V), lo, hi, members, h->h_from.data(), h->h_to.data(),
+                                         iters, o, nullptr));
+            chi[c] = o.max_chi2; tot[c] = o.chi2_total;
+            meta[c] = make_int4(o.iterations, o.tries, o.flags, o.evals);
+        }
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+        HIPCHK(hipMemcpy(h->d_chi + offsets[s], chi.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_chitot + offsets[s], tot.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_meta + offsets[s], meta.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
+    }
+    return IPC_OK;
+}
+
 extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_solve_rows: NULL handle");
@@ -748,16 +794,16 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
     // pass 1: count
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS, st));
-    const dim3 pgrid((N + 255) / 256, N), pblock(256);
+    const dim3 pgrid((N + 255) / 256, std::min(N, 32768)), pblock(256);
     hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
                        h->d_offsets, (int2*)nullptr, 0);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
     HIPCHK(hipMemcpyAsync(counts, h->d_counters, sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (counts[nb] || counts[(kMaxBins + 1) + nb])
-        return fail(IPC_ERR_LIMIT, "a sub-problem spans more than %d poses (largest kernel variant in the policy)",
-                    bc.cap[nb - 1]);
+    // cells whose chain is longer than the largest kernel variant of the policy go through the cluster
+    // solver below (one at a time, state in HBM: no length limit) instead of failing the matrix
+    const unsigned n_long = counts[nb] + counts[(kMaxBins + 1) + nb];
     size_t total = 0;
     for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
     if (total > h->cells_cap) {
@@ -832,10 +878,14 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
         HIPCHK(hipEventRecord(h->ev_join[k], h->side[k]));
         HIPCHK(hipStreamWaitEvent(st, h->ev_join[k], 0));
     }
+    if (n_long) {
+        if (int rc = solve_long_cells(h, st, nb, counts, offsets)) return rc;
+    }
     HIPCHK(hipEventRecord(h->ev1, st));
     h->ev_valid = true;
     h->last_launches = launches;
     h->last_cells = (int)total;
+    h->last_long_cells = (int)n_long;
     if (total)
         hipLaunchKernelGGL(k_scatter_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
                            h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, world, words,
@@ -853,7 +903,7 @@ extern "C" int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
-    hipLaunchKernelGGL(k_assemble, dim3((words + 63) / 64, N), dim3(64), 0, st, N, words, world, rpr, h->d_lo,
+    hipLaunchKernelGGL(k_assemble, dim3((words + 63) / 64, std::min(N, 32768)), dim3(64), 0, st, N, words, world, rpr, h->d_lo,
                        h->d_hi, (const unsigned long long*)d_gathered, (unsigned long long*)d_bits);
     HIPCHK(hipGetLastError());
     return IPC_OK;
@@ -930,6 +980,40 @@ extern "C" int ipc_cell_info(ipc_engine_t* h, ipc_cell_info_t* out, int capacity
         o.max_chi2 = chi[c]; o.chi2_total = tot[c];
         o.iterations = meta[c].x; o.tries = meta[c].y; o.flags = meta[c].z; o.evals = meta[c].w;
     }
+    return IPC_OK;
+}
+
+// counts over the cell records of the last solve: [0] flags & 2 (linear solve failed), [1] not terminated
+// (ran to the iteration cap), [2] NaN max chi2
+__global__ void k_report(int n, const int4* meta, const double* chi, unsigned* out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int4 m = meta[c];
+    if (m.z & 2) atomicAdd(&out[0], 1u);
+    if (!(m.z & 1) && !(m.z & 2)) atomicAdd(&out[1], 1u);
+    if (chi[c] != chi[c]) atomicAdd(&out[2], 1u);
+}
+
+extern "C" int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out)
+{
+    if (!h || !out) return fail(IPC_ERR_ARG, "ipc_solve_report: NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    memset(out, 0, sizeof *out);
+    out->cells = h->last_cells;
+    out->long_cells = h->last_long_cells;
+    if (h->last_cells <= 0) return IPC_OK;
+    unsigned host[3] = {0, 0, 0};
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * 3, h->own_stream));
+    hipLaunchKernelGGL(k_report, dim3((h->last_cells + 255) / 256), dim3(256), 0, h->own_stream, h->last_cells, h->d_meta,
+                       h->d_chi, h->d_counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, h->d_counters, sizeof host, hipMemcpyDeviceToHost, h->own_stream));
+    HIPCHK(hipStreamSynchronize(h->own_stream));
+    out->failed_cells = (int)host[0];
+    out->capped_cells = (int)host[1];
+    out->nan_cells = (int)host[2];
     return IPC_OK;
 }
 

@@ -188,6 +188,11 @@ std::vector<uint8_t> IPC::agreementCheckAll(const std::vector<Edge>& cands)
     _max_consensus_set.clear();
     if (N == 0) return acc;
     check(ipc_run(_h, nullptr, acc.data()));
+    ipc_solve_report_t rep{};
+    check(ipc_solve_report(_h, &rep));
+    if (rep.failed_cells || rep.long_cells)
+        std::cerr << "ipc_amd: " << rep.failed_cells << " of " << rep.cells << " cells stopped on a non-positive pivot, "
+                  << rep.long_cells << " went through the long-chain fallback" << std::endl;
     check(ipc_candidate_order(_h, _order.data()));
     for (int k : _order)
         if (acc[k]) _max_consensus_set.push_back(k);
@@ -292,8 +297,11 @@ SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph&
     IPC ipc(g, odom, cfg, device);
     std::cout << "Starting simulation of incremental dataset -> Displaying relative status : " << std::endl;
     std::cout << "S = " << cfg.s_factor << " | TH = " << cfg.fast_reject_th << std::endl;
+    // Default = the reference's own algorithm (per-candidate agreementCheck from the current state,
+    // src/simulation.cpp:34-47), so the tester prints the consensus set the reference would.  The batched
+    // consistency matrix + set-max (a re-formulation) is opt-in: IPC_AMD_MODE=matrix.
     const char* mode_env = std::getenv("IPC_AMD_MODE");
-    const bool incremental = mode_env && std::string(mode_env) == "incremental";
+    const bool incremental = !(mode_env && std::string(mode_env) == "matrix");
     auto t0 = std::chrono::steady_clock::now();
     std::vector<uint8_t> bucket;
     if (incremental) {                                                            // simulation.cpp:34-47

@@ -100,8 +100,8 @@ struct SimulationResult {
 // runs the consensus, prints the reference's console lines, writes cfg.output (trajectory after
 // the final map optimisation) and "<output minus 3 chars>PR"
 // (src/simulation.cpp:91-105).  Environment IPC_AMD_MODE selects the consensus formulation:
-// "matrix" (default: batched consistency matrix + set-max) or "incremental" (the reference's
-// per-candidate agreementCheck loop on the GPU).
+// "incremental" (default: the reference's per-candidate agreementCheck loop on the GPU, same accepted
+// set as the reference's algorithm) or "matrix" (batched consistency matrix + set-max).
 SimulationResult simulating_incremental_data(const Config& cfg, const PoseGraph& g, const std::vector<Edge>& odom,
                                              const std::vector<Edge>& loops, int device = 0);
 

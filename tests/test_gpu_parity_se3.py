@@ -132,3 +132,44 @@ def test_se3_variant_choice_does_not_change_decisions(oracle, monkeypatch):
         assert np.array_equal(acc, ref[1]), name
         a, b = cells["max_chi2"], ref[2]["max_chi2"]
         assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-12)), name
+
+
+def test_chain_beyond_every_cell_kernel_goes_through_the_cluster_fallback(oracle):
+    """An 8000-pose SE(3) trajectory (the size of the reference's cfg/3D/GRID_params.yaml) with one
+    full-span loop: its cells span more poses than the largest cell kernel (4096), so they are solved by
+    the cluster-solver fallback instead of failing the whole matrix (round 1: IPC_ERR_LIMIT)."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import unpack_bits
+    O = oracle
+    g = synth.chain3d(seed=8, V=8000, n_loops=12, max_span=150)
+    # one true loop over (almost) the whole trajectory, measured from the odometry itself (zero residual)
+    poses = O.propagate(3, g.odom_meas)
+    a, b = 5, 7995
+    Ra, ta = poses[a][:9].reshape(3, 3), poses[a][9:]
+    Rb, tb = poses[b][:9].reshape(3, 3), poses[b][9:]
+    Rab, tab = Ra.T @ Rb, Ra.T @ (tb - ta)
+    q = synth._R_to_quat(Rab)
+    full = np.concatenate([tab, q])
+    g = synth.PoseGraph(3, g.vertices, g.odom_meas, g.odom_info, np.vstack([g.loop_ids, [[a, b]]]).astype(np.int32),
+                        np.vstack([g.loop_meas, full]), np.vstack([g.loop_info, g.loop_info[:1]]), dict(g.meta))
+    eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=6.251)
+    bits, acc = eng.run()
+    rep = eng.solve_report()
+    cells = eng.cell_info()
+    L = cells["hi"] - cells["lo"]
+    assert rep["long_cells"] == int((L > 4096).sum()) and rep["long_cells"] >= 2
+    assert rep["failed_cells"] == 0
+    k = eng.N - 1
+    C = unpack_bits(bits, eng.N)
+    assert C[k, k] == 1 and acc[k] == 1                          # the zero-residual full-span loop agrees
+    long_cells = cells[L > 4096]
+    pick = np.concatenate([np.nonzero(L > 4096)[0][:3], np.nonzero(L <= 4096)[0][:6]])
+    mx, its, _ = O.pair_cells_mt(3, g.odom_meas, g.odom_info, cfg.s_factor, poses, g.loop_ids, g.loop_meas, g.loop_info,
+                                 cells["i"][pick], cells["j"][pick], cfg.fast_reject_iter_base, cfg.slow_reject_iter_base,
+                                 len(pick))
+    for c, m in zip(cells[pick], mx):
+        th = cfg.fast_reject_th if c["i"] == c["j"] else cfg.slow_reject_th
+        assert (not (m > th)) == (not (c["max_chi2"] > th)), (c, m)
+        assert abs(m - c["max_chi2"]) <= 1e-5 * max(abs(m), 1e-9) + 1e-9, (c, m)
+    assert len(long_cells) == rep["long_cells"]
+    assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))

@@ -107,7 +107,8 @@ def test_generate_dataset_matches_python_generator(built, tmp_path, dim, n, seed
 @pytest.mark.parametrize("dim", [2, 3])
 def test_tester_outputs_match_python_path(built, tmp_path, dim):
     cfg, vals = _write_cfg(tmp_path, dim)
-    r = subprocess.run([built[dim], "-c", cfg], capture_output=True, text=True)
+    env = dict(os.environ, IPC_AMD_MODE="matrix")                  # the batched formulation (opt-in)
+    r = subprocess.run([built[dim], "-c", cfg], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert "Size of MAX consistent set" in r.stdout and "Precision" in r.stdout and "Recall" in r.stdout
     exp = np.load(os.path.join(GOLD, ("small_se2" if dim == 2 else "small_se3") + "_expected.npz"))
@@ -146,11 +147,11 @@ def test_tester_outputs_match_python_path(built, tmp_path, dim):
 
 @pytest.mark.gpu
 def test_tester_incremental_mode_matches_python_path(built, tmp_path):
-    """IPC_AMD_MODE=incremental runs the reference's per-candidate loop (src/simulation.cpp:34-47)."""
+    """The tester's default is the reference's own per-candidate loop (src/simulation.cpp:34-47)."""
     from ipc_amd import graphio
     from ipc_amd.consensus import IPC, Config
     cfg, vals = _write_cfg(tmp_path, 2)
-    env = dict(os.environ, IPC_AMD_MODE="incremental")
+    env = {k: v for k, v in os.environ.items() if k != "IPC_AMD_MODE"}
     r = subprocess.run([built[2], "-c", cfg], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     g = graphio.read_g2o(vals["dataset"])
