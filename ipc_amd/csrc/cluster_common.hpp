@@ -134,7 +134,7 @@ struct LoopTables {
 // Ops:  evaluate_committed(chi) | linearize(bb, bHb, hh, bh, info) | blend(alpha, c, bma)
 //       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
 template <class Ops>
-hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out)
+hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term_eps = 0.0, int n_edges = 1)
 {
     out = ClusterOut{};
     double currentChi;
@@ -142,6 +142,7 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out)
     out.chi2_initial = currentChi;
     double delta = 1e4;
     const int maxTrials = 100;
+    bool lastGN = false;
     for (int it = 0; it < iterations; ++it) {
         double bb, bHb, hh, bh;
         int info = 0;
@@ -149,6 +150,11 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out)
         if (info != 0) { out.flags |= 2; out.iterations = it + 1; break; }
         const double hHh = bh;                        // H h_gn = b
         const double alpha = bb / bHb, hsdNorm = std::sqrt(alpha * alpha * bb), hgnNorm = std::sqrt(hh);
+        if (lastGN && hgnNorm < delta && std::fabs(bh) * n_edges < term_eps * currentChi) {   // converged (Se2View::term_eps)
+            out.iterations = it + 1; out.tries += maxTrials; out.flags |= 1;
+            break;
+        }
+        const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
         do {
@@ -194,6 +200,7 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out)
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         out.iterations = it + 1;
         out.tries += numTries;
         if (numTries == maxTrials || !goodStep) { out.flags |= 1; break; }

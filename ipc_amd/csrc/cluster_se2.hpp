@@ -354,6 +354,7 @@ __global__ void gk_update(ClusterDev D, double p, double q)
 class ClusterSolver2 {
 public:
     ~ClusterSolver2() { release(); }
+    double term_eps = 0.0;             // convergence shortcut of the trial loop (Se2View::term_eps)
 
     // Solve chain lo..hi (records `chain`) + the loops `members` (indices into the candidate
     // records; ids in from/to are global vertex ids), starting from the poses `src` (global
@@ -538,7 +539,7 @@ inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int
         IPC_CL_CHK(hipMemcpyAsync(xp[k], sp[k] + lo, sizeof(double) * (L + 1), hipMemcpyDeviceToDevice, st));
     nblk_ = (L + nl + 1 + kGB - 1) / kGB;            // indices 0 .. L+nl
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
-    return cluster_dogleg(*this, iterations, out);
+    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl);
 }
 
 }  // namespace ipc

@@ -477,6 +477,7 @@ __global__ void gk3_update(ClusterDev3 D, double p, double q)
 class ClusterSolver3 {
 public:
     ~ClusterSolver3() { release(); }
+    double term_eps = 0.0;             // convergence shortcut of the trial loop (Se2View::term_eps)
 
     // src: poses [12][src_ld] with global indexing; the optimised poses stay in result() ([12][ld()],
     // local indexing 0..hi-lo).
@@ -658,7 +659,7 @@ inline hipError_t ClusterSolver3::solve(hipStream_t st, const double* chain, int
                                 hipMemcpyDeviceToDevice, st));
     nblk_ = (L + nl + 1 + kGB - 1) / kGB;
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
-    return cluster_dogleg(*this, iterations, out);
+    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl);
 }
 
 }  // namespace ipc

@@ -468,6 +468,7 @@ static hipError_t launch_se3_lds(int nl, int idx, int n, hipStream_t st, const S
 struct ipc_engine {
     int dim = 2, V = 0, N = 0, device = 0;
     ipc_params_t prm{};
+    double term_eps = 1e-13;                           // IPC_TERMINATE_EPS (0: g2o's literal trial loop), Se2View::term_eps
     BinPlan plan{};
     hipStream_t own_stream = nullptr;
     // chain
@@ -526,6 +527,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     {
         std::string perr;
         if (!make_plan(h->plan, dim, perr)) { delete h; return fail(IPC_ERR_ARG, "%s", perr.c_str()); }
+    }
+    if (const char* te = getenv("IPC_TERMINATE_EPS")) {
+        if (*te) h->term_eps = atof(te);
+        if (!(h->term_eps >= 0) || h->term_eps > 1e-6) { delete h; return fail(IPC_ERR_ARG, "IPC_TERMINATE_EPS must be in [0, 1e-6]"); }
     }
     const int E = n_vertices - 1;
     const int ms = dim == 2 ? 3 : 7, is = dim == 2 ? 6 : 21, nf = dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
@@ -715,6 +720,7 @@ static Se2View make_view(const ipc_engine* h)
     P.chain_rec = h->d_chain_rec;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     P.dbg = nullptr;
+    P.term_eps = h->term_eps;
 #if defined(IPC_PHASE_TIMING)
     static double* dbgbuf = nullptr;
     if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
@@ -729,6 +735,7 @@ static Se3View make_view3(const ipc_engine* h)
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
     P.chain_rec = h->d_chain_rec;
     P.chain_blk = h->d_chain_blk;
+    P.term_eps = h->term_eps;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
     return P;
 }
@@ -1114,7 +1121,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
             HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 12 * (size_t)h->V));
             HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
         }
-        if (!h->cluster3) h->cluster3 = new ClusterSolver3();
+        if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; }
         return IPC_OK;
     }
     if (!h->d_open) {
@@ -1125,7 +1132,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         HIPCHK(hipMemcpyAsync(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
-    if (!h->cluster) h->cluster = new ClusterSolver2();
+    if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; }
     return IPC_OK;
 }
 

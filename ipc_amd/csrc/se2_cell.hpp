@@ -63,6 +63,19 @@ struct Se2View {
     const int* cand_from;     // candidate "from" / "to" vertex ids
     const int* cand_to;
     double* dbg;              // debug side channel (NULL in production)
+    // Convergence test of the dog-leg (0 = off: g2o's literal loop).  g2o has none: a converged problem leaves
+    // optimize() only through Terminate, i.e. after an iteration whose trials all fail -- about 40 evaluated
+    // trials (delta halves until no pose moves any more), more than half of all residual passes of a matrix.
+    // With the Gauss-Newton step h of the current linearisation, an edge's chi2 moves by at most
+    // 2 sqrt(chi2_e h^T H h) = 2 sqrt(chi2_e b^T h).  The solve stops (with the Terminate flag) when
+    //   * the previous iteration accepted the full Gauss-Newton step at its first trial and this one's lies
+    //     inside the trust region (Newton regime: steps shrink quadratically), and
+    //   * |b^T h| * #edges < term_eps * chi2_total   (chi2_max >= chi2_total / #edges),
+    // i.e. when the next step could change no edge's chi2 by more than 2 sqrt(term_eps) relative (6e-7
+    // worst case with the default 1e-13).  A problem that is still moving on trust-region-limited steps
+    // (slow crawls along a flat valley, up to the iteration cap) runs g2o's loop unchanged: cutting those
+    // short would move their per-edge chi2 by ~5e-5.
+    double term_eps;
 };
 
 struct SolveParams {
@@ -293,6 +306,8 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                                Se2Shared<W, M, NL>& sh, CellResult& res)
 {
     constexpr int NS = NL * 3;
+    const double term_scale = P.term_eps / (double)(L + NL);   // 0: the test is off
+    bool lastGN = false;
     constexpr int KR = 2 + NS + NS * (NS + 1) / 2;   // b^T b, b^T H b, d, S (upper triangle)
     static_assert(KR <= 32 && W <= 16, "reduction scratch layout");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -942,7 +957,12 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
         }
 
         IPC_TICK(tmC)
+        // converged (Se2View::term_eps): in the Newton regime (the last iteration took the full Gauss-Newton
+        // step at its first trial) and one more such step cannot move any edge's chi2 by more than
+        // 2 sqrt(term_eps) relative; g2o would still run its trial loop to Terminate
+        if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
+        const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
         bool haveBlend = false;
@@ -1060,6 +1080,7 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         it_done = it + 1;
         tries_total += numTries;
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }

@@ -128,6 +128,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 {
     static_assert(W == 1 || W == 2 || W == 4, "one, two or four cooperating waves per cell");
     constexpr int NS = NL * 3;
+    const double term_scale = P.term_eps / (double)(L + NL);   // 0: the test is off
+    bool lastGN = false;
     const int lane = threadIdx.x & 63;
     const int wsub = W > 1 ? ((threadIdx.x >> 6) & (W - 1)) : 0;  // wave of the cell
     const int gl = wsub * 64 + lane;                 // lane index within the cell
@@ -832,7 +834,12 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             hHh = bh;
         }
         IPC_WTICK(tmC)
+        // converged (Se2View::term_eps): in the Newton regime (the last iteration took the full Gauss-Newton
+        // step at its first trial) and one more such step cannot move any edge's chi2 by more than
+        // 2 sqrt(term_eps) relative; g2o would still run its trial loop to Terminate
+        if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
+        const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
         do {
@@ -898,6 +905,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         it_done = it + 1;
         tries_total += numTries;
         IPC_WTICK(tmT)

@@ -40,6 +40,7 @@ struct Se3View {
     int cstride;
     const int* cand_from;
     const int* cand_to;
+    double term_eps;          // convergence shortcut of the trial loop, see Se2View::term_eps
 };
 
 struct Pose3 { double R[9]; double t[3]; };
@@ -311,6 +312,8 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                                Se3Shared<W, M, NL>& sh, CellResult3& res)
 {
     constexpr int NS = NL * 6;
+    const double term_scale = P.term_eps / (double)(L + NL);   // 0: the test is off
+    bool lastGN = false;
     constexpr int NSS = NS * (NS + 1) / 2;
     constexpr int KR = 2 + NS + NSS;                 // b^T b, b^T H b, d, S upper: 29 (diag) / 92 (pair)
     constexpr int NG = (KR + 15) / 16;               // packed groups of 16
@@ -1019,7 +1022,12 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             hHh = bh;
         }
 
+        // converged (Se2View::term_eps): in the Newton regime (the last iteration took the full Gauss-Newton
+        // step at its first trial) and one more such step cannot move any edge's chi2 by more than
+        // 2 sqrt(term_eps) relative; g2o would still run its trial loop to Terminate
+        if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
+        const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
         do {
@@ -1130,6 +1138,7 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         it_done = it + 1;
         tries_total += numTries;
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }

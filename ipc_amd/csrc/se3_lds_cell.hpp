@@ -90,6 +90,8 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
 {
     static_assert(W == 1 || W == 4, "one wave per cell, or the whole workgroup of four");
     constexpr int NS = NL * 6;
+    const double term_scale = P.term_eps / (double)(L + NL);   // 0: the test is off
+    bool lastGN = false;
     const int lane = threadIdx.x & 63;
     const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // wave of the team
     const int wbase = wave * 64 * M;                  // poses wbase+1 .. wbase+64M belong to this wave
@@ -1050,7 +1052,12 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             hHh = bh;
         }
 
+        // converged (Se2View::term_eps): in the Newton regime (the last iteration took the full Gauss-Newton
+        // step at its first trial) and one more such step cannot move any edge's chi2 by more than
+        // 2 sqrt(term_eps) relative; g2o would still run its trial loop to Terminate
+        if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
+        const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
         do {
@@ -1108,6 +1115,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         it_done = it + 1;
         tries_total += numTries;
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }

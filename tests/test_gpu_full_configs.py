@@ -190,3 +190,29 @@ def test_full_size_c5_properties_and_aimed_parity(oracle):
     pick, info = _sample(cells, cfg, n_random=max(200, 40 * cores), max_cap=4 * cores)
     print("C5 sample:", info)
     _oracle_compare(oracle, g, cfg, cells, pick)
+
+
+@pytest.mark.parametrize("name", ["C1", "C4s"])
+def test_convergence_test_against_the_literal_g2o_loop(name, monkeypatch):
+    """IPC_TERMINATE_EPS=0 runs g2o's literal loop (every solve ends through ~40 failing trials); the default
+    stops a solve in the Newton regime once one more Gauss-Newton step cannot move an edge's chi2 by more
+    than 2 sqrt(1e-13) (Se2View::term_eps).  Same decisions, same accepted set, chi2 within 1e-6."""
+    from bench import build_workload
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = build_workload(name)
+    res = {}
+    for mode, val in (("literal", "0"), ("default", None)):
+        if val is None:
+            monkeypatch.delenv("IPC_TERMINATE_EPS", raising=False)
+        else:
+            monkeypatch.setenv("IPC_TERMINATE_EPS", val)
+        eng = IPC(g, cfg, device=0)
+        bits, acc = eng.run()
+        c = eng.cell_info()
+        res[mode] = (bits.copy(), acc.copy(), c[np.lexsort((c["j"], c["i"]))])
+        eng.close()
+    a, b = res["literal"], res["default"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    rel = np.abs(a[2]["max_chi2"] - b[2]["max_chi2"]) / np.maximum(np.abs(a[2]["max_chi2"]), 1e-300)
+    assert float(rel.max()) <= 1e-6
+    assert b[2]["evals"].sum() < 0.8 * a[2]["evals"].sum()        # the test does remove residual passes

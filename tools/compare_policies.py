@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Run one workload under two kernel policies (IPC_SE3_POLICY / IPC_SE2_POLICY values) and compare the
-per-cell results: decisions, max chi2, iteration counts.  usage: compare_policies.py C4m block default"""
+per-cell results: decisions, max chi2, iteration counts.  usage: compare_policies.py C4m block default
+(or environment settings: compare_policies.py C2 "IPC_TERMINATE_EPS=0" default)"""
 import os
 import sys
 import time
@@ -12,11 +13,20 @@ from bench import build_workload
 from ipc_amd.consensus import IPC
 
 
+_touched = set()
+
+
 def run(g, cfg, pol):
+    """pol: "default", a policy string, or KEY=VALUE[,KEY=VALUE...] environment settings."""
     key = "IPC_SE%d_POLICY" % g.dim
-    if pol == "default":
-        os.environ.pop(key, None)
-    else:
+    for k in _touched | {key}:
+        os.environ.pop(k, None)
+    if "=" in pol:
+        for kv in pol.split(";"):
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+            _touched.add(k)
+    elif pol != "default":
         os.environ[key] = pol
     eng = IPC(g, cfg, device=0)
     t0 = time.perf_counter()
@@ -46,6 +56,8 @@ def main(workload, pa, pb):
     conv = (ca["flags"] & 1).astype(bool) & (cb["flags"] & 1).astype(bool)
     print("decisions differing: %d of %d; accepted sets equal: %s; bits equal: %s" % (
         int((da != db).sum()), len(ca), bool(np.array_equal(aa, ab)), bool(np.array_equal(ba, bb))))
+    print("evals per cell: %.2f vs %.2f; iterations per cell %.2f vs %.2f" % (ca["evals"].mean(), cb["evals"].mean(),
+                                                                             ca["iterations"].mean(), cb["iterations"].mean()))
     print("max rel chi2 diff (both terminated): %.3e; (all): %.3e; iterations equal on %.4f of the cells; NaN a/b %d/%d" % (
         float(np.nanmax(rel[conv])) if conv.any() else 0.0, float(np.nanmax(rel)), float((ca["iterations"] == cb["iterations"]).mean()),
         int(np.isnan(ca["max_chi2"]).sum()), int(np.isnan(cb["max_chi2"]).sum())))
