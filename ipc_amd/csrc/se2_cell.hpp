@@ -1074,7 +1074,8 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             if (!goodStep) {
                 if (stepType == 0) {
                     // identical GN trial repeats while hgnNorm < delta: each halves delta
-                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
+                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;             // every later (halved) SD step is a no-op too
                 }

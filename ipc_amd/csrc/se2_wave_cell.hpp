@@ -138,7 +138,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     // ---- exchange among the W waves of the cell: every wave posts up to 8 doubles and waits for
     // all others; peer(o, k) then reads wave o's value k.  Also the cell's barrier. ----
 #ifdef IPC_PHASE_TIMING
-    unsigned long long tmA = 0, tmB1 = 0, tmB2 = 0, tmC = 0, tmT = 0, tmW = 0, tm0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tmA = 0, tmB1 = 0, tmB2 = 0, tmC = 0, tmT = 0, tmW = 0, tmK = 0, tm0 = __builtin_amdgcn_s_memtime();
 #define IPC_WTICK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tm0; tm0 = t_; }
 #else
 #define IPC_WTICK(acc)
@@ -893,13 +893,16 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
+                IPC_WTICK(tmT)
                 sweep(IntC<2>{}, anyBig, pcoef, qcoef, trial, stepType == 0, false);
+                IPC_WTICK(tmK)
             }
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
                 if (stepType == 0) {
-                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
+                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }
@@ -918,7 +921,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         atomicAdd(d + 4, tmT); atomicAdd(d + 5, tmW);
         atomicAdd(d + 6, (unsigned long long)it_done); atomicAdd(d + 7, (unsigned long long)evals);
         atomicAdd(d + 8, (unsigned long long)it_done * (unsigned long long)L);
-        atomicAdd(d + 9, 1ull);
+        atomicAdd(d + 9, 1ull); atomicAdd(d + 10, tmK); atomicAdd(d + 11, (unsigned long long)(evals - 1 - it_done));
     }
 #endif
 

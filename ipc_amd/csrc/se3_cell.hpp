@@ -1132,7 +1132,8 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
                 if (stepType == 0) {
-                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
+                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }

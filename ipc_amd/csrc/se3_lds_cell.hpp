@@ -1109,7 +1109,8 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
                 if (stepType == 0) {
-                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
+                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }

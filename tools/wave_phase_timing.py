@@ -14,13 +14,13 @@ eng = IPC(g, cfg, device=0)
 eng.run()
 out = np.zeros(2048, dtype=np.uint64)
 eng.lib.ipc_dbg_read(eng.h, out.ctypes.data_as(C.c_void_p), 2048)
-print("variant   cells   iters   %A   %B1(partials)  %B2(solve)  %C   %trials   wait%(of all)   ticks/iter  ticks/(iter*pose)*1e3")
+print("variant   cells   iters   %A   %B1(partials)  %B2(solve)  %C   %trials  %commit  wait%(of all)   ticks/iter  ticks/(iter*pose)*1e3  rejected-trials/iter")
 for W in (1, 2, 4):
     for M in range(1, 16):
         d = out[64 + 16 * (M + 16 * (W - 1)):][:16].astype(np.float64)
         if d[9] == 0:
             continue
-        tot = d[0] + d[1] + d[2] + d[3] + d[4]
-        print("%s%-3d %8d %9d  %5.1f %5.1f %5.1f %5.1f %5.1f   %5.1f   %8.1f  %8.2f" % (
+        tot = d[0] + d[1] + d[2] + d[3] + d[4] + d[10]
+        print("%s%-3d %8d %9d  %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f   %5.1f   %8.1f  %8.2f  %6.3f" % (
             {1: "w", 2: "p", 4: "q"}[W], M, d[9], d[6], 100 * d[0] / tot, 100 * d[1] / tot, 100 * d[2] / tot,
-            100 * d[3] / tot, 100 * d[4] / tot, 100 * d[5] / tot, tot / d[6], 1e3 * tot / d[8]))
+            100 * d[3] / tot, 100 * d[4] / tot, 100 * d[10] / tot, 100 * d[5] / tot, tot / d[6], 1e3 * tot / d[8], d[11] / d[6]))
