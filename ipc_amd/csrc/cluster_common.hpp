@@ -193,9 +193,10 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term
             if (rho > 0.75) delta = std::max(delta, 3 * hdlNorm);
             else if (rho < 0.25) delta *= 0.5;
             if (!goodStep) {
-                if (stepType == 0) {
-                    if (rho != rho) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
-                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                if (rho != rho) {
+                    numTries = maxTrials;       // NaN gain ratio: g2o leaves delta alone, so every retry is this same trial
+                } else if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }

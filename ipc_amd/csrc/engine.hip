@@ -713,19 +713,26 @@ extern "C" int ipc_initial_poses(ipc_engine_t* h, double* poses_out)
     return IPC_OK;
 }
 
+// debug side channel of the cell kernels (phase timing builds only; NULL in production)
+static double* dbg_buffer()
+{
+#if defined(IPC_PHASE_TIMING)
+    static double* dbgbuf = nullptr;
+    if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
+    return dbgbuf;
+#else
+    return nullptr;
+#endif
+}
+
 static Se2View make_view(const ipc_engine* h)
 {
     Se2View P;
     P.chain = h->d_chain; P.estride = h->estride; P.pose0 = h->d_pose0; P.V = h->V;
     P.chain_rec = h->d_chain_rec;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
-    P.dbg = nullptr;
+    P.dbg = dbg_buffer();
     P.term_eps = h->term_eps;
-#if defined(IPC_PHASE_TIMING)
-    static double* dbgbuf = nullptr;
-    if (!dbgbuf) { hipMalloc(&dbgbuf, sizeof(double) * 8 * 4096); hipMemset(dbgbuf, 0, sizeof(double) * 8 * 4096); }
-    P.dbg = dbgbuf;
-#endif
     return P;
 }
 
@@ -737,6 +744,7 @@ static Se3View make_view3(const ipc_engine* h)
     P.chain_blk = h->d_chain_blk;
     P.term_eps = h->term_eps;
     P.cand = h->d_cand; P.cstride = h->cstride; P.cand_from = h->d_from; P.cand_to = h->d_to;
+    P.dbg = dbg_buffer();
     return P;
 }
 

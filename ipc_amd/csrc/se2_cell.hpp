@@ -1072,10 +1072,11 @@ __device__ void se2_solve_cell(const Se2View& P, int lo_abs, int L, const int (&
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
-                if (stepType == 0) {
+                if (nonLinearGain != nonLinearGain) {
+                    numTries = maxTrials;       // NaN gain ratio: g2o leaves delta alone, so every retry is this same trial
+                } else if (stepType == 0) {
                     // identical GN trial repeats while hgnNorm < delta: each halves delta
-                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
-                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;             // every later (halved) SD step is a no-op too
                 }

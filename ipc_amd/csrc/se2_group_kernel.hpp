@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_group_kernel(Se2Vi
         for (int o = 0; o < W; ++o) {
             if (o == wsub) continue;
             while (__hip_atomic_load(&box->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
-                __builtin_amdgcn_s_sleep(1);
+                IPC_SPIN_WAIT();
         }
         wave_sync();
         c = (unsigned)box->data[0][seq & 1][0];

@@ -48,6 +48,16 @@ struct PairBox {
     int flag[4];
 };
 
+// what a wave does between two polls of its partner's mailbox flag
+#ifndef IPC_SPIN_SLEEP
+#define IPC_SPIN_SLEEP 1
+#endif
+#if IPC_SPIN_SLEEP > 0
+#define IPC_SPIN_WAIT() __builtin_amdgcn_s_sleep(IPC_SPIN_SLEEP)
+#else
+#define IPC_SPIN_WAIT() asm volatile("s_nop 0")
+#endif
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -161,7 +171,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             for (int o = 0; o < W; ++o) {
                 if (o == wsub) continue;
                 while (__hip_atomic_load(&box->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq < 0)
-                    __builtin_amdgcn_s_sleep(1);
+                    IPC_SPIN_WAIT();
             }
 #ifdef IPC_PHASE_TIMING
             tmW += __builtin_amdgcn_s_memtime() - tw0;
@@ -840,7 +850,8 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
         const double deltaAtEntry = delta;
-        bool goodStep = false;
+        bool goodStep = false, dlReady = false;
+        double dlC = 0.0, dlBma = 0.0;
         int numTries = 0;
         do {
             ++numTries;
@@ -850,16 +861,21 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
             else {
                 stepType = 2;
-                double p0 = 0.0, p1 = 0.0;            // c = hsd.(hgn-hsd), |hgn-hsd|^2
+                // c = hsd.(hgn-hsd) and |hgn-hsd|^2 do not depend on delta: reduced once per iteration, reused by
+                // every later dog-leg trial of the same iteration (same bits)
+                if (!dlReady) {
+                    double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-                for (int s = 0; s < M; ++s) {
-                    const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
-                    const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
-                    p0 += sx * ax + sy * ay + sth * ath;
-                    p1 += ax * ax + ay * ay + ath * ath;
+                    for (int s = 0; s < M; ++s) {
+                        const double sx = alpha * bx[s], sy = alpha * by[s], sth = alpha * bth[s];
+                        const double ax = hx[s] - sx, ay = hy[s] - sy, ath = hth[s] - sth;
+                        p0 += sx * ax + sy * ay + sth * ath;
+                        p1 += ax * ax + ay * ay + ath * ath;
+                    }
+                    cell_sum2(p0, p1, dlC, dlBma);
+                    dlReady = true;
                 }
-                double c, bma;
-                cell_sum2(p0, p1, c, bma);
+                const double c = dlC, bma = dlBma;
                 const double hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
                 else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
@@ -900,9 +916,10 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
-                if (stepType == 0) {
-                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
-                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                if (nonLinearGain != nonLinearGain) {
+                    numTries = maxTrials;       // NaN gain ratio: g2o leaves delta alone, so every retry is this same trial
+                } else if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }

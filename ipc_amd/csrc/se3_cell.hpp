@@ -41,6 +41,7 @@ struct Se3View {
     const int* cand_from;
     const int* cand_to;
     double term_eps;          // convergence shortcut of the trial loop, see Se2View::term_eps
+    double* dbg;              // debug side channel (NULL in production)
 };
 
 struct Pose3 { double R[9]; double t[3]; };
@@ -1131,9 +1132,10 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
-                if (stepType == 0) {
-                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
-                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                if (nonLinearGain != nonLinearGain) {
+                    numTries = maxTrials;       // NaN gain ratio: g2o leaves delta alone, so every retry is this same trial
+                } else if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }

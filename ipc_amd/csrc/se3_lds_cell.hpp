@@ -97,9 +97,17 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
     const int wbase = wave * 64 * M;                  // poses wbase+1 .. wbase+64M belong to this wave
     const int jbase = wbase + lane + 1;               // pose of slot 0
 
+#ifdef IPC_PHASE_TIMING
+    unsigned long long tmA = 0, tmB1 = 0, tmB2 = 0, tmC = 0, tmT = 0, tmK = 0, tmBar = 0, tm0 = __builtin_amdgcn_s_memtime();
+#define IPC3_TICK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tm0; tm0 = t_; }
+#define IPC3_SYNC() do { const unsigned long long b_ = __builtin_amdgcn_s_memtime(); __syncthreads(); tmBar += __builtin_amdgcn_s_memtime() - b_; } while (0)
+#else
+#define IPC3_TICK(acc)
+#define IPC3_SYNC() __syncthreads()
+#endif
     int phase = 0;
     auto tbar = [&]() {
-        if constexpr (W > 1) __syncthreads();
+        if constexpr (W > 1) IPC3_SYNC();
         else wave_sync3();
     };
     // team totals of K per-lane values, the same bits on every lane of the team
@@ -109,7 +117,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
         if constexpr (W > 1) {
             const int buf = phase & 1;
             if (lane == 0) { sh.red[buf][wave][0] = a; sh.red[buf][wave][1] = b2; }
-            __syncthreads();
+            IPC3_SYNC();
             ++phase;
             double x = sh.red[buf][0][0], y = sh.red[buf][0][1];
 #pragma unroll
@@ -230,7 +238,11 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
     int jv = jbase;
     auto opaque = [&]() { asm volatile("" : "+v"(jv)); };
     auto rec_of = [&](int s) -> const double2* {
+#ifdef IPC_DBG_SAMEREC   // timing experiment only (wrong results): every slot of every wave reads the same 64 records
+        const unsigned e = (unsigned)(lo_abs + lane + 0 * (jv + s));
+#else
         const unsigned e = (unsigned)(lo_abs + jv - 1 + s * 64);   // edge k joins pose k -> k+1
+#endif
         return P.chain_blk + ((size_t)(e >> 6) * (kSe3BlkPairs * 64) + (e & 63u));
     };
     auto ld_rz = [&](const double2* pl, double* Rz, double* tz) {
@@ -367,7 +379,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
 #pragma unroll
                         for (int k = 0; k < 3; ++k) sh.hi_pose[buf][wave][4 + k] = last.t[k];
                     }
-                    __syncthreads();
+                    IPC3_SYNC();
                     ++phase;
                     carry = ld_pose(0);
                     if (wave > 0) {
@@ -440,7 +452,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 if constexpr (W > 1) {
                     const int buf = phase & 1;
                     if (lane == 0) { sh.red[buf][wave][0] = part; sh.red[buf][wave][1] = nn; }
-                    __syncthreads();
+                    IPC3_SYNC();
                     ++phase;
                     part = sh.red[buf][0][0]; nn = sh.red[buf][0][1];
 #pragma unroll
@@ -466,6 +478,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
     // ---------------- initial errors (consensus_utils.cpp:11) ----------------
     int evals = 1;
     double currentChi = sweep(std::integral_constant<int, 0>{}, 0, 0.0, 0.0, cur);
+    IPC3_TICK(tmT)
 
     double delta = 1e4;
     const int maxTrials = 100;
@@ -511,7 +524,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
 #pragma unroll
                     for (int k = 0; k < 6; ++k) sh.lo_vec[buf][wave][k] = m0[k];
                 }
-                __syncthreads();
+                IPC3_SYNC();
                 ++phase;
                 if (wave + 1 < W) {
 #pragma unroll
@@ -551,6 +564,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 IPC3_FENCE();
             }
         }
+        IPC3_TICK(tmA)
         // ---- phase B: b^T b, b^T H b and the capacitance partials; solve on wave 0 ----
         // (formulas: se3_cell.hpp phase B)
         double bb, bHb, alpha, hsdNorm;
@@ -768,6 +782,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             }
             flush(cls, true);
             tbar();
+            IPC3_TICK(tmB1)
             const int bufS = phase & 1;
             if (wave == 0) {
                 constexpr int RS = NS + 1;
@@ -905,6 +920,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             hsdNorm = sqrt(alpha * alpha * bb);
         }
 
+        IPC3_TICK(tmB2)
         // ---- phase C: u = -Sg Phi^T n - e, rho = D^-1 u, world-frame prefix sums -> h ----
         double hgnNorm, bh, hHh;
         opaque();
@@ -1006,7 +1022,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                     sh.scan[buf][wave][7] = sh.t1[pq] - sh.t1[pe];
                     sh.scan[buf][wave][8] = sh.t2[pq] - sh.t2[pe];
                 }
-                __syncthreads();
+                IPC3_SYNC();
                 ++phase;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
@@ -1052,13 +1068,15 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             hHh = bh;
         }
 
+        IPC3_TICK(tmC)
         // converged (Se2View::term_eps): in the Newton regime (the last iteration took the full Gauss-Newton
         // step at its first trial) and one more such step cannot move any edge's chi2 by more than
         // 2 sqrt(term_eps) relative; g2o would still run its trial loop to Terminate
         if (lastGN && hgnNorm < delta && fabs(bh) < term_scale * currentChi) { it_done = it + 1; tries_total += maxTrials; flags |= 1; break; }
         // ---- trial loop ----
         const double deltaAtEntry = delta;
-        bool goodStep = false;
+        bool goodStep = false, dlReady = false;
+        double dlC = 0.0, dlBma = 0.0;
         int numTries = 0;
         do {
             ++numTries;
@@ -1068,18 +1086,23 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
             else {
                 stepType = 2;
-                double p0 = 0.0, p1 = 0.0;
+                // delta-independent: reduced once per iteration, reused by its later dog-leg trials (same bits)
+                if (!dlReady) {
+                    double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-                for (int s = 0; s < M; ++s) {
+                    for (int s = 0; s < M; ++s) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const double sk = alpha * b[s][k], ak = h[s][k] - sk;
-                        p0 += sk * ak;
-                        p1 += ak * ak;
+                        for (int k = 0; k < 6; ++k) {
+                            const double sk = alpha * b[s][k], ak = h[s][k] - sk;
+                            p0 += sk * ak;
+                            p1 += ak * ak;
+                        }
                     }
+                    team_sum2(p0, p1);
+                    dlC = p0; dlBma = p1;
+                    dlReady = true;
                 }
-                team_sum2(p0, p1);
-                const double c = p0, bma = p1, hsdSq = alpha * alpha * bb;
+                const double c = dlC, bma = dlBma, hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
                 else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
             }
@@ -1103,14 +1126,17 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 goodStep = true;
                 currentChi = newChi;
                 cur = trial;
+                IPC3_TICK(tmT)
                 sweep(std::integral_constant<int, 2>{}, stepType, pcoef, qcoef, trial);
+                IPC3_TICK(tmK)
             }
             if (rho_gt(0.75)) delta = fmax(delta, 3 * hdlNorm);
             else if (rho_lt(0.25)) delta *= 0.5;
             if (!goodStep) {
-                if (stepType == 0) {
-                    if (nonLinearGain != nonLinearGain) numTries = maxTrials;   // NaN gain ratio: g2o leaves delta alone, every retry is the same trial
-                    else while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                if (nonLinearGain != nonLinearGain) {
+                    numTries = maxTrials;       // NaN gain ratio: g2o leaves delta alone, so every retry is this same trial
+                } else if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
                 } else if (stepType == 1 && !anyChanged) {
                     numTries = maxTrials;
                 }
@@ -1119,8 +1145,19 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
         lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         it_done = it + 1;
         tries_total += numTries;
+        IPC3_TICK(tmT)
         if (numTries == maxTrials || !goodStep) { flags |= 1; break; }
     }
+#ifdef IPC_PHASE_TIMING
+    if (lane == 0 && (wave == 0 || wave == W - 1) && P.dbg) {
+        // slot: 1024 + 32 * (M + 16 * (W > 1)) + 16 * (wave != 0 || W == 1 ? 0 : 1) ... wave 0 first, last wave second
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(P.dbg) + 1024 + 32 * (M + 16 * (W > 1 ? 1 : 0)) + (wave == 0 ? 0 : 16);
+        atomicAdd(d + 0, tmA); atomicAdd(d + 1, tmB1); atomicAdd(d + 2, tmB2); atomicAdd(d + 3, tmC);
+        atomicAdd(d + 4, tmT); atomicAdd(d + 5, tmK); atomicAdd(d + 6, tmBar);
+        atomicAdd(d + 7, (unsigned long long)it_done); atomicAdd(d + 8, (unsigned long long)evals);
+        atomicAdd(d + 9, (unsigned long long)it_done * (unsigned long long)L); atomicAdd(d + 10, 1ull);
+    }
+#endif
 
     // ---- per-edge chi2 (consensus_utils.cpp:15-19) ----
     tbar();
