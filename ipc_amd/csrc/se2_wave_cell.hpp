@@ -148,6 +148,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
     // ---- exchange among the W waves of the cell: every wave posts up to 8 doubles and waits for
     // all others; peer(o, k) then reads wave o's value k.  Also the cell's barrier. ----
 #ifdef IPC_PHASE_TIMING
+    unsigned long long gnEvals = 0, gnRejected = 0, nBig = 0, tmBig = 0, tmSmall = 0;
     unsigned long long tmA = 0, tmB1 = 0, tmB2 = 0, tmC = 0, tmT = 0, tmW = 0, tmK = 0, tm0 = __builtin_amdgcn_s_memtime();
 #define IPC_WTICK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tm0; tm0 = t_; }
 #else
@@ -897,10 +898,19 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             }
             const bool anyBig = __ballot(big) != 0ull;
             const int trial = cur ^ 1;
+#ifdef IPC_PHASE_TIMING
+            const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
             const double newChi = sweep(IntC<1>{}, anyBig, pcoef, qcoef, trial, stepType == 0, stepType == 1);
+#ifdef IPC_PHASE_TIMING
+            if (anyBig) { ++nBig; tmBig += __builtin_amdgcn_s_memtime() - tb0; } else { tmSmall += __builtin_amdgcn_s_memtime() - tb0; }
+#endif
             const bool anyChanged = stepType == 1 ? sweepChanged : true;
             ++evals;
             const double nonLinearGain = currentChi - newChi;
+#ifdef IPC_PHASE_TIMING
+            if (stepType == 0) { ++gnEvals; if (!(linearGain > 0 ? nonLinearGain > 0 : nonLinearGain < 0)) ++gnRejected; }
+#endif
             if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
             const bool linPos = linearGain > 0;
             auto rho_gt = [&](double t) { return linPos ? nonLinearGain > t * linearGain : nonLinearGain < t * linearGain; };
@@ -938,7 +948,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         atomicAdd(d + 4, tmT); atomicAdd(d + 5, tmW);
         atomicAdd(d + 6, (unsigned long long)it_done); atomicAdd(d + 7, (unsigned long long)evals);
         atomicAdd(d + 8, (unsigned long long)it_done * (unsigned long long)L);
-        atomicAdd(d + 9, 1ull); atomicAdd(d + 10, tmK); atomicAdd(d + 11, (unsigned long long)(evals - 1 - it_done));
+        atomicAdd(d + 9, 1ull); atomicAdd(d + 10, tmK); atomicAdd(d + 11, (unsigned long long)(evals - 1 - it_done)); atomicAdd(d + 12, gnEvals); atomicAdd(d + 13, gnRejected); atomicAdd(d + 14, nBig); atomicAdd(d + 15, tmBig); atomicAdd(d + 1024, tmSmall);
     }
 #endif
 
