@@ -364,7 +364,7 @@ struct BinPlan {
     int latency_variant[kMaxBins];
     int latency_below[kMaxBins];
 };
-static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
+static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,w13,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
 // engine streams + the caller's stream = the runtime's four hardware queues for SE2; the long SE3
 // launches gain a little from a fourth engine stream
 static const int kDefaultSideStreams2 = 2, kDefaultSideStreams3 = 3;

@@ -64,6 +64,7 @@ struct Se3Lds {
     double w0gam[NL][36];
     double w0aug[NL * 6][NL * 6 + 1];
     double w0mu[NL * 6];
+    double w0lq[2];           // b^T H b terms of the loop edges
     int cell;                 // the team's current cell (W > 1: broadcast from wave 0)
     int pad_;
 };
@@ -784,8 +785,13 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
             tbar();
             IPC3_TICK(tmB1)
             const int bufS = phase & 1;
+            // The capacitance system is set up by the whole team (W > 1): wave 0 sums the class totals while wave 1
+            // builds the Gamma_l, then every wave computes its share of the NS x (NS+1) augmented matrix; only the
+            // Gauss-Jordan elimination (a serial chain) runs on wave 0 alone, next to the loops' own b^T H b terms
+            // on wave 1.  With one wave doing all of it the other three idled for 10-17 % of an iteration.
+            constexpr int RS = NS + 1;
+            constexpr int kGamWave = W > 1 ? 1 : 0;
             if (wave == 0) {
-                constexpr int RS = NS + 1;
                 // totals: [0] b^T b, [1] b^T H b, [2..8) W_1, [8..29) M_11; pair: [29..35) W_2, [35..56) M_22, [56..77) M_12
                 auto clsum = [&](int c, int k) -> double {
                     double t = sh.tot[0][c][k];
@@ -793,17 +799,17 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                     for (int w = 1; w < W; ++w) t += sh.tot[w][c][k];
                     return t;
                 };
-                {
-                    // 27 values per target group, one lane each
-                    const int k = lane;
-                    if (k < 27) {
-                        const double c1 = clsum(1, k), c3 = NL == 2 ? clsum(3, k) : 0.0, c2 = NL == 2 ? clsum(2, k) : 0.0;
-                        sh.w0tot[2 + k] = c1 + c3;
-                        if constexpr (NL == 2) { sh.w0tot[29 + k] = c2 + c3; if (k >= 6) sh.w0tot[56 + (k - 6)] = c3; }
-                    }
-                    if (k == 27) sh.w0tot[1] = (clsum(1, 27) + (NL == 2 ? clsum(2, 27) : 0.0)) + (NL == 2 ? clsum(3, 27) : 0.0);
-                    if (k == 28) sh.w0tot[0] = (clsum(1, 28) + (NL == 2 ? clsum(2, 28) : 0.0)) + (NL == 2 ? clsum(3, 28) : 0.0);
+                // 27 values per target group, one lane each
+                const int k = lane;
+                if (k < 27) {
+                    const double c1 = clsum(1, k), c3 = NL == 2 ? clsum(3, k) : 0.0, c2 = NL == 2 ? clsum(2, k) : 0.0;
+                    sh.w0tot[2 + k] = c1 + c3;
+                    if constexpr (NL == 2) { sh.w0tot[29 + k] = c2 + c3; if (k >= 6) sh.w0tot[56 + (k - 6)] = c3; }
                 }
+                if (k == 27) sh.w0tot[1] = (clsum(1, 27) + (NL == 2 ? clsum(2, 27) : 0.0)) + (NL == 2 ? clsum(3, 27) : 0.0);
+                if (k == 28) sh.w0tot[0] = (clsum(1, 28) + (NL == 2 ? clsum(2, 28) : 0.0)) + (NL == 2 ? clsum(3, 28) : 0.0);
+            }
+            if (wave == kGamWave) {
                 // Gamma_l entries (one lane per entry, one round per loop)
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
@@ -835,10 +841,15 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                         sh.w0gam[l][lane] = q.sigma * g;
                     }
                 }
-                wave_sync3();
+            }
+            tbar();
+            // augmented matrix: entry idx = q0 + team lane, NS * RS entries over the team's 64 W lanes
+            {
+                constexpr int TL = 64 * W;
+                const int tl = wave * 64 + lane;
 #pragma unroll
-                for (int q0 = 0; q0 < NS * RS; q0 += 64) {
-                    const int idx = q0 + lane;
+                for (int q0 = 0; q0 < NS * RS; q0 += TL) {
+                    const int idx = q0 + tl;
                     if (idx < NS * RS) {
                         const int r = idx / RS, c = idx % RS;
                         const int l1 = r / 6, i = r % 6;
@@ -867,7 +878,10 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                         sh.w0aug[r][c] = vv;
                     }
                 }
-                wave_sync3();
+            }
+            tbar();
+            if (wave == kGamWave && lane < NL) sh.w0lq[lane] = loop_quad(lane, bufB);
+            if (wave == 0) {
                 // Gauss-Jordan, one row per lane
                 double row[RS];
                 const int rl = lane < NS ? lane : 0;
@@ -890,10 +904,6 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 }
                 if (lane < NS) sh.w0mu[lane] = row[NS];
                 wave_sync3();
-                double lq = 0.0;
-                if (lane < NL) lq = loop_quad(lane, bufB);
-                double bHbTot = sh.w0tot[1] + read_lane(lq, 0);
-                if (NL == 2) bHbTot += read_lane(lq, 1);
                 if (lane < NS) {
                     const int l = lane / 6, c = lane % 6;
                     double t = 0.0;
@@ -903,7 +913,7 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
                 }
                 if (lane == 0) {
                     sh.sol[bufS][NS] = sh.w0tot[0];
-                    sh.sol[bufS][NS + 1] = bHbTot;
+                    sh.sol[bufS][NS + 1] = sh.w0tot[1];
                     sh.sol[bufS][NS + 2] = okS ? 1.0 : 0.0;
                 }
             }
@@ -914,7 +924,8 @@ __device__ __forceinline__ void se3_lds_solve(const Se3View& P, int lo_abs, int 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) nu[l][k] = sh.sol[bufS][6 * l + k];
             bb = sh.sol[bufS][NS];
-            bHb = sh.sol[bufS][NS + 1];
+            bHb = sh.sol[bufS][NS + 1] + sh.w0lq[0];
+            if (NL == 2) bHb += sh.w0lq[1];
             if (sh.sol[bufS][NS + 2] == 0.0) { flags |= 2; break; }
             alpha = bb / bHb;
             hsdNorm = sqrt(alpha * alpha * bb);
