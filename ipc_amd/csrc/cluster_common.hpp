@@ -50,12 +50,12 @@ __global__ void gk_sum(const double* partial, int nblocks, int K, double* scal, 
     scal[off + k] = acc;
 }
 
-// in-place inclusive prefix sums over indices 1..L of K arrays (row length ld), one workgroup
+// in-place inclusive prefix sums over indices 1..L of K arrays (row length ld), one workgroup per array
 __global__ __launch_bounds__(1024) void gk_scan(double* arr, int K, int L, int ld)
 {
     __shared__ double wsum[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int k = 0; k < K; ++k) {
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
         double* a = arr + (size_t)k * ld;
         double carry = 0.0;
         for (int base = 1; base <= L; base += 1024) {

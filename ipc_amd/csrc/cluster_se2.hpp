@@ -387,7 +387,7 @@ private:
     void release()
     {
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_scal_);
-        hipFree(d_int_); hipFree(d_info_);
+        hipFree(d_int_);
         if (h_scal_) hipHostFree(h_scal_);
         d_edge_ = d_loop_ = d_S_ = d_partial_ = d_scal_ = nullptr; d_int_ = d_info_ = nullptr; h_scal_ = nullptr;
         capL_ = capNl_ = 0;
@@ -395,8 +395,8 @@ private:
     hipError_t ensure(int L, int nl);
     hipError_t fetch(int n)
     {
-        IPC_CL_CHK(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double) * n, hipMemcpyDeviceToHost, st_));
-        IPC_CL_CHK(hipMemcpyAsync(h_scal_ + 12, d_info_, sizeof(int), hipMemcpyDeviceToHost, st_));
+        (void)n;                     // scalars [0, 12) and the solver's info word at [12] travel in one copy
+        IPC_CL_CHK(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double) * 13, hipMemcpyDeviceToHost, st_));
         return hipStreamSynchronize(st_);
     }
     void sum_partials(int K, int off)
@@ -418,7 +418,7 @@ inline hipError_t ClusterSolver2::ensure(int L, int nl)
     if (!h_scal_) {
         IPC_CL_CHK(hipHostMalloc(&h_scal_, sizeof(double) * 16));
         IPC_CL_CHK(hipMalloc(&d_scal_, sizeof(double) * 16));
-        IPC_CL_CHK(hipMalloc(&d_info_, sizeof(int)));
+        d_info_ = reinterpret_cast<int*>(d_scal_ + 12);
     }
     if (L > capL_ || nl > capNl_) {
         const int nL = std::max(L, capL_), nN = std::max(nl, capNl_);
@@ -428,7 +428,7 @@ inline hipError_t ClusterSolver2::ensure(int L, int nl)
         const size_t ld = (size_t)nL + 2;
         IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (43 * ld + ld + nN)));
         IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (27 * (size_t)nN + 8)));
-        IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * (3 * (size_t)nN + 1) * (3 * (size_t)nN)));
+        IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * 2 * (3 * (size_t)nN + 1) * (3 * (size_t)nN)));   // system + factor
         IPC_CL_CHK(hipMalloc(&d_partial_, sizeof(double) * 4 * ((nL + nN + 1 + kGB) / kGB + 1)));
         IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
         capL_ = nL; capNl_ = nN;
@@ -446,16 +446,16 @@ inline hipError_t ClusterSolver2::linearize(double& bb, double& bHb, double& hh,
     sum_partials(1, 0);
     hipLaunchKernelGGL(gk_bHb_psi, grid, block, 0, st_, D);
     sum_partials(1, 1);
-    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.ps, 9, L, ld);
+    hipLaunchKernelGGL(gk_scan, dim3(9), dim3(1024), 0, st_, D.ps, 9, L, ld);
     hipLaunchKernelGGL(gk_assemble, dim3((nl + 63) / 64, nl), dim3(64), 0, st_, D);
-    IPC_CL_CHK(chol_solve_device(D.S, 3 * nl, D.rhs, d_info_, st_));
+    IPC_CL_CHK(chol_solve_device(D.S, D.S + (size_t)(3 * nl + 1) * (3 * nl), 3 * nl, D.rhs, d_info_, st_));
     hipLaunchKernelGGL(gk_nu, dim3((nl + 63) / 64), dim3(64), 0, st_, D);
     hipLaunchKernelGGL(gk_events, dim3((L + 2 + kGB - 1) / kGB), block, 0, st_, D);
-    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.nd, 3, L, ld);
+    hipLaunchKernelGGL(gk_scan, dim3(3), dim3(1024), 0, st_, D.nd, 3, L, ld);
     hipLaunchKernelGGL(gk_rho, grid, block, 0, st_, D);
     hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.sc, 1, L, ld);
     hipLaunchKernelGGL(gk_term, grid, block, 0, st_, D);
-    hipLaunchKernelGGL(gk_scan, dim3(1), dim3(1024), 0, st_, D.sc + ld, 2, L, ld);
+    hipLaunchKernelGGL(gk_scan, dim3(2), dim3(1024), 0, st_, D.sc + ld, 2, L, ld);
     hipLaunchKernelGGL(gk_h, grid, block, 0, st_, D);
     sum_partials(2, 2);
     IPC_CL_CHK(hipGetLastError());

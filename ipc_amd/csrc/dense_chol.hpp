@@ -2,8 +2,11 @@
 // Right-looking blocked Cholesky, column major, lower triangle.  The right-hand side rides
 // along as an extra ROW (row n) of the (n+1) x n array, so the forward substitution falls out of
 // the factorisation itself (row n of the factor is y = L^-1 d); only L^T x = y is a separate pass.
-// Sizes are small (tens .. a few thousand), so the kernels favour few launches and coalesced
-// column accesses over peak FLOPs.
+// Sizes are small (tens .. a few hundred unknowns) and one factorisation sits on the critical path of
+// every dog-leg iteration of the incremental mode, so the kernels are built for LATENCY: one launch
+// per block column (the diagonal block is factored redundantly by every workgroup, each trailing tile
+// solves the panel rows it needs itself), the factor goes to a second array so that no workgroup
+// reads what another one writes, and the triangular kernels run in registers with v_readlane.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -13,24 +16,50 @@ namespace ipc {
 
 constexpr int kCB = 32;      // block-column width
 
-// Block column k0: factor the diagonal block (every workgroup redundantly, in LDS) and solve the
-// panel rows below it, 64 rows per workgroup (workgroup 0 writes the diagonal block back).
-__global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k0, int* info)
+// 1 / sqrt(x) to full precision: v_rsq_f64 + two Newton steps
+__device__ __forceinline__ double rsqrt_newton(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+// One block column k0 .. k0+nb of the factorisation, one workgroup per 64 x 64 tile (bx >= by) of the trailing
+// matrix (rows k1 .. n, row n = right-hand side; columns k1 .. n-1):
+//   1. every workgroup loads the nb x nb diagonal block and its first wave factors it in registers (lane r holds
+//      row r; column c reaches the other rows through v_readlane, so the 32 elimination steps are straight-line
+//      code without LDS round trips);
+//   2. waves 0 / 1 solve the 64 panel rows of the tile's row block / column block against it (one row per lane);
+//   3. the tile is updated, C -= Ai Aj^T (4 x 4 per thread);
+//   4. tiles of the first tile column (by == 0) write their panel rows to the factor Lf, tile (0, 0) the
+//      diagonal block as well.
+// A (trailing matrix, updated in place tile by tile) and Lf (factor, written once) are different arrays.
+__global__ __launch_bounds__(256) void chol_step(double* A, double* Lf, int n, int ld, int k0, int nb, int* info)
 {
     __shared__ double D[kCB][kCB + 1];
     __shared__ double Dinv[kCB];
-    const int lane = threadIdx.x;
-    const int nb = min(kCB, n - k0);
-    for (int idx = lane; idx < kCB * kCB; idx += 64) {
+    __shared__ double Ai[kCB][64 + 1], Aj[kCB][64 + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k1 = k0 + nb;
+    const int i0 = k1 + blockIdx.x * 64, j0 = k1 + blockIdx.y * 64;
+    if (blockIdx.y > blockIdx.x) return;
+    for (int idx = tid; idx < kCB * kCB; idx += 256) {
         const int r = idx % kCB, c = idx / kCB;
         D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + c) * ld + k0 + r] : (r == c ? 1.0 : 0.0);
     }
+    // panel rows of this tile (original values), one row per lane: waves 0 / 1 keep them in registers
+    double x[kCB];
+    const int prow = wave == 0 ? i0 + lane : j0 + lane;
+    const bool pvalid = wave == 0 ? prow <= n : prow < n;          // row n (rhs) only ever is a tile ROW
+    if (wave < 2) {
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? A[(size_t)(k0 + c) * ld + prow] : 0.0;
+    }
     __syncthreads();
-    // Factor the diagonal block in registers: lane r holds row r; column c of the factor reaches the
-    // other rows through v_readlane (constant lane), so the 32 elimination steps are straight-line
-    // code without LDS round trips.  Rows >= nb are identity rows.
     bool ok = true;
-    {
+    if (wave == 0) {
+        // rows >= nb are identity rows
         const int r = lane & 31;
         double row[kCB];
 #pragma unroll
@@ -39,70 +68,49 @@ __global__ __launch_bounds__(64) void chol_panel(double* A, int n, int ld, int k
         for (int c = 0; c < kCB; ++c) {
             const double piv = read_lane(row[c], c);
             if (!(piv > 0)) ok = false;
-            const double d = sqrt(piv), inv = 1.0 / d;
-            const double lrc = r == c ? d : (r > c ? row[c] * inv : 0.0);
+            const double inv = rsqrt_newton(piv);
+            const double lrc = r == c ? piv * inv : (r > c ? row[c] * inv : 0.0);
             row[c] = lrc;
+            if (lane == c) Dinv[c] = inv;
 #pragma unroll
             for (int cc = c + 1; cc < kCB; ++cc) {
                 const double lcc = read_lane(lrc, cc);       // L[cc][c]
-                if (r >= cc) row[cc] = fma(-lrc, lcc, row[cc]);
+                // (rows r < cc pick up garbage above the diagonal, which nothing reads: lrc is forced to 0 for
+                // r < c, the pivot is read from lane c, and only the lower triangle is written back)
+                row[cc] = fma(-lrc, lcc, row[cc]);
             }
         }
-        __syncthreads();
         if (lane < kCB) {
 #pragma unroll
             for (int c = 0; c < kCB; ++c) D[r][c] = row[c];
         }
-        // reciprocal of the diagonal, one division per lane instead of one per row and column
-#pragma unroll
-        for (int c = 0; c < kCB; ++c) {
-            const double dcc = read_lane(row[c], c);
-            if (lane == c) Dinv[c] = 1.0 / dcc;
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        for (int idx = lane; idx < kCB * kCB; idx += 64) {
-            const int r = idx % kCB, c = idx / kCB;
-            if (r < nb && c < nb && r >= c) A[(size_t)(k0 + c) * ld + k0 + r] = D[r][c];
-        }
-        if (!ok && lane == 0) *info = k0 + 1;
-        return;
-    }
-    const int row = k0 + nb + (blockIdx.x - 1) * 64 + lane;
-    if (row > n) return;                                   // row n = right-hand side
-    double x[kCB];
-#pragma unroll
-    for (int c = 0; c < kCB; ++c) x[c] = c < nb ? A[(size_t)(k0 + c) * ld + row] : 0.0;
-#pragma unroll
-    for (int c = 0; c < kCB; ++c) {
-        double v = x[c];
-#pragma unroll
-        for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
-        x[c] = v * Dinv[c];
-        // Store at once: the LDS reads of the unrolled triangle are ordered memory operations, the
-        // arithmetic is not -- left free it sinks towards one block of stores at the end, every
-        // loaded operand stays live and the kernel spills 600 registers.  A store per column pins
-        // the arithmetic of that column in place.
-        if (c < nb) A[(size_t)(k0 + c) * ld + row] = x[c];
-    }
-}
-
-// Trailing update C[i][j] -= sum_p A[i][k0+p] A[j][k0+p] for k1 <= j <= i, i <= n (row n = rhs),
-// j < n; 64 x 64 tile per workgroup, 4 x 4 per thread.
-__global__ __launch_bounds__(256) void chol_update(double* A, int n, int ld, int k0, int nb)
-{
-    if (blockIdx.y > blockIdx.x) return;
-    __shared__ double Ai[kCB][64], Aj[kCB][64];
-    const int k1 = k0 + nb;
-    const int i0 = k1 + blockIdx.x * 64, j0 = k1 + blockIdx.y * 64;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < kCB * 64; idx += 256) {
-        const int p = idx >> 6, r = idx & 63;
-        Ai[p][r] = (p < nb && i0 + r <= n) ? A[(size_t)(k0 + p) * ld + i0 + r] : 0.0;
-        Aj[p][r] = (p < nb && j0 + r < n) ? A[(size_t)(k0 + p) * ld + j0 + r] : 0.0;
     }
     __syncthreads();
+    if (wave < 2) {
+        double (*P)[64 + 1] = wave == 0 ? Ai : Aj;
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) {
+            double v = x[c];
+#pragma unroll
+            for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
+            x[c] = v * Dinv[c];
+            // Store at once: the LDS reads of the unrolled triangle are ordered memory operations, the
+            // arithmetic is not -- left free it sinks towards one block of stores at the end, every
+            // loaded operand stays live and the kernel spills.  A store per column pins the arithmetic.
+            P[c][lane] = c < nb ? x[c] : 0.0;
+            if (wave == 0 && blockIdx.y == 0 && c < nb && pvalid) Lf[(size_t)(k0 + c) * ld + prow] = x[c];
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int idx = tid; idx < kCB * kCB; idx += 256) {
+            const int r = idx % kCB, c = idx / kCB;
+            if (r < nb && c < nb && r >= c) Lf[(size_t)(k0 + c) * ld + k0 + r] = D[r][c];
+        }
+        // info: 0 = positive definite so far, else 1 + the first block column with a non-positive pivot
+        if (tid == 0) { if (k0 == 0) *info = ok ? 0 : 1; else if (!ok && *info == 0) *info = k0 + 1; }
+    }
+    __syncthreads();
+    if (j0 >= n) return;                                    // (a tile column of right-hand-side rows only)
     const int tx = tid & 15, ty = tid >> 4;
     double acc[4][4];
 #pragma unroll
@@ -131,8 +139,10 @@ __global__ __launch_bounds__(256) void chol_update(double* A, int n, int ld, int
     }
 }
 
-// L^T x = y with y = row n of the factored array; one workgroup
-__global__ __launch_bounds__(1024) void chol_backsolve(const double* A, int n, int ld, double* x)
+// L^T x = y with y = row n of the factor; one workgroup.  Per block column (from the last one): the part of the
+// sums that involves already solved unknowns is a reduction over rows (16 waves, coalesced column reads), the
+// nb x nb triangle is solved in registers by the first wave (constant-lane v_readlane, no LDS round trips).
+__global__ __launch_bounds__(1024) void chol_backsolve(const double* Lf, int n, int ld, double* x)
 {
     __shared__ double D[kCB][kCB + 1];
     __shared__ double t[kCB];
@@ -142,22 +152,26 @@ __global__ __launch_bounds__(1024) void chol_backsolve(const double* A, int n, i
         const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
         for (int c = wave; c < nb; c += 16) {
             double acc = 0.0;
-            for (int r = k1 + lane; r < n; r += 64) acc += A[(size_t)(k0 + c) * ld + r] * x[r];
+            for (int r = k1 + lane; r < n; r += 64) acc += Lf[(size_t)(k0 + c) * ld + r] * x[r];
             acc = wave_sum(acc);
             if (lane == 0) t[c] = acc;
         }
         for (int idx = tid; idx < kCB * kCB; idx += 1024) {
             const int r = idx % kCB, c = idx / kCB;
-            D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
+            D[r][c] = (r < nb && c < nb && r >= c) ? Lf[(size_t)(k0 + c) * ld + k0 + r] : (r == c ? 1.0 : 0.0);
         }
         __syncthreads();
         if (wave == 0) {
-            double v = lane < nb ? A[(size_t)(k0 + lane) * ld + n] - t[lane] : 0.0;
-            const double dinv = lane < nb ? 1.0 / D[lane][lane] : 0.0;      // one division per lane, not per step
-            for (int r = nb - 1; r >= 0; --r) {
-                const double xr = __shfl(v, r, 64) * __shfl(dinv, r, 64);
-                if (lane == r) v = xr;
-                else if (lane < r) v -= D[r][lane] * xr;
+            const int l = lane & 31;
+            double v = l < nb ? Lf[(size_t)(k0 + l) * ld + n] - t[l] : 0.0;
+            const double dinv = 1.0 / D[l][l];              // one division per lane, not per step
+            double col[kCB];                                // col[r] = L[r][l]: what unknown r takes away from row l
+#pragma unroll
+            for (int r = 0; r < kCB; ++r) col[r] = D[r][l];
+#pragma unroll
+            for (int r = kCB - 1; r >= 0; --r) {
+                const double xr = read_lane(v, r) * read_lane(dinv, r);
+                v = l == r ? xr : (l < r ? fma(-col[r], xr, v) : v);
             }
             if (lane < nb) x[k0 + lane] = v;
         }
@@ -166,20 +180,17 @@ __global__ __launch_bounds__(1024) void chol_backsolve(const double* A, int n, i
     }
 }
 
-// factor + solve; the solution lands in x[0..n)
-inline hipError_t chol_solve_device(double* A, int n, double* x, int* d_info, hipStream_t st)
+// factor + solve; A is the (n+1) x n system (destroyed), Lf a second array of the same size that receives the
+// factor; the solution lands in x[0..n)
+inline hipError_t chol_solve_device(double* A, double* Lf, int n, double* x, int* d_info, hipStream_t st)
 {
     const int ld = n + 1;
-    hipError_t e = hipMemsetAsync(d_info, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
     for (int k0 = 0; k0 < n; k0 += kCB) {
         const int nb = n - k0 < kCB ? n - k0 : kCB, k1 = k0 + nb;
-        const int rows = n + 1 - k1;
-        hipLaunchKernelGGL(chol_panel, dim3(1 + (rows + 63) / 64), dim3(64), 0, st, A, n, ld, k0, d_info);
         const int nti = (n + 1 - k1 + 63) / 64, ntj = (n - k1 + 63) / 64;
-        if (ntj > 0) hipLaunchKernelGGL(chol_update, dim3(nti, ntj), dim3(256), 0, st, A, n, ld, k0, nb);
+        hipLaunchKernelGGL(chol_step, dim3(nti, ntj > 0 ? ntj : 1), dim3(256), 0, st, A, Lf, n, ld, k0, nb, d_info);
     }
-    hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, (const double*)A, n, ld, x);
+    hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, (const double*)Lf, n, ld, x);
     return hipGetLastError();
 }
 
