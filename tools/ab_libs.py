@@ -29,7 +29,8 @@ def run(lib, workload, reps, out):
     c = eng.cell_info()
     c = c[np.lexsort((c["j"], c["i"]))]
     th = np.where(c["i"] == c["j"], cfg.fast_reject_th, cfg.slow_reject_th)
-    np.savez(out, bits=bits, acc=acc, chi=c["max_chi2"], it=c["iterations"], ev=c["evals"], ms=best, th=th, n=len(c))
+    np.savez(out, bits=bits, acc=acc, chi=c["max_chi2"], it=c["iterations"], ev=c["evals"], ms=best, th=th, n=len(c),
+             ci=c["i"], cj=c["j"], L=c["hi"] - c["lo"], fl=c["flags"])
 
 
 if __name__ == "__main__":
@@ -63,3 +64,10 @@ if __name__ == "__main__":
             line += "  | vs first: identical=%s decisions differing=%d accepted-set equal=%s max rel chi2 diff (same iteration count) %.2e" % (
                 bool(ident), dec, bool(np.array_equal(a["acc"], r["acc"])), float(np.nanmax(rel[conv])) if conv.any() else 0.0)
         print(line, flush=True)
+        if k and not ident:
+            a = res[0]
+            d = np.nonzero((a["it"] != r["it"]) | ~((a["chi"] == r["chi"]) | (np.isnan(a["chi"]) & np.isnan(r["chi"]))))[0]
+            print("   %d cells differ; first ones (i j L | it chi2 evals flags first | second):" % len(d))
+            for q in d[:12]:
+                print("   %5d %5d %5d | %4d %.17g %4d %d | %4d %.17g %4d %d" % (a["ci"][q], a["cj"][q], a["L"][q], a["it"][q], a["chi"][q], a["ev"][q], a["fl"][q],
+                                                                        r["it"][q], r["chi"][q], r["ev"][q], r["fl"][q]))
