@@ -269,47 +269,82 @@ __global__ void k_scatter_bits(int ncells, const int2* cells, const double* chi,
     if (ok) atomicOr(&upper[(size_t)(cc.x / world) * words + (cc.y >> 6)], 1ull << (cc.y & 63));
 }
 
-__global__ void k_assemble(int N, int words, int world, int rpr, const int* lo, const int* hi,
-                           const unsigned long long* gathered, unsigned long long* bits)
+// Symmetric N x N bit matrix from the gathered upper-triangle rows (row a of rank a % world at gathered row
+// (a % world) * rpr + a / world).  One wave per tile of 64 rows x one 64-bit word: lane l owns candidate j = 64 w + l
+// (its interval and its diagonal bit), a row's overlap test is ONE compare per lane and a ballot, and the common
+// case -- no candidate of the word overlaps row i (reference src/consensus.cpp:157-159: then C[i][j] = C[i][i] & C[j][j])
+// -- is a single select of the word of diagonal bits; only overlapping pairs read their solved bit.
+__global__ __launch_bounds__(256) void k_assemble(int N, int words, int world, int rpr, const int* lo, const int* hi,
+                                                  const unsigned long long* gathered, unsigned long long* bits)
 {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= words) return;
-    for (int i = blockIdx.y; i < N; i += gridDim.y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = blockIdx.x;
     auto U = [&](int a, int c) -> unsigned {        // a <= c
         const unsigned long long word = gathered[((size_t)(a % world) * rpr + a / world) * words + (c >> 6)];
         return (unsigned)((word >> (c & 63)) & 1ull);
     };
-    const int loi = lo[i], hii = hi[i];
-    const unsigned di = U(i, i);
-    unsigned long long out = 0;
-    for (int b = 0; b < 64; ++b) {
-        const int j = w * 64 + b;
-        if (j >= N) break;
-        unsigned bit;
-        if (j == i) bit = di;
-        else if (min(hii, hi[j]) - max(loi, lo[j]) > 0) bit = U(min(i, j), max(i, j));
-        else bit = di & U(j, j);
-        out |= (unsigned long long)bit << b;
-    }
-    bits[(size_t)i * words + w] = out;
+    const int j = w * 64 + lane;
+    const bool vj = j < N;
+    const int loj = vj ? lo[j] : 0, hij = vj ? hi[j] : 0;
+    const unsigned long long Dword = __ballot(vj && U(j, j));
+    for (int rb = blockIdx.y * 4 + wave; rb * 64 < N; rb += gridDim.y * 4) {
+        const int ir = rb * 64 + lane;                 // this lane's row of the tile
+        const bool vr = ir < N;
+        const int lor = vr ? lo[ir] : 0, hir = vr ? hi[ir] : 0;
+        const unsigned long long dmask = __ballot(vr && U(ir, ir));
+        const int nrows = min(64, N - rb * 64);
+        unsigned long long mine = 0ull;
+        for (int r = 0; r < nrows; ++r) {
+            const int i = rb * 64 + r;
+            const int loi = __builtin_amdgcn_readlane(lor, r), hii = __builtin_amdgcn_readlane(hir, r);
+            unsigned long long word = ((dmask >> r) & 1ull) ? Dword : 0ull;
+            const bool ov = vj && j != i && (min(hii, hij) - max(loi, loj) > 0);
+            const unsigned long long ovmask = __ballot(ov);
+            if (ovmask) {
+                const bool bit = ov && U(min(i, j), max(i, j));
+                word = (word & ~ovmask) | __ballot(bit);
+            }
+            if (lane == r) mine = word;
+        }
+        if (vr) bits[(size_t)ir * words + w] = mine;
     }
 }
 
-// Greedy set-max: candidates in processing order, 16 per round (one wave each).
+// Greedy set-max: candidates in processing order, 16 per round (one wave each).  Candidates whose own cell failed
+// can never join, so the order list is first compacted to those with a set diagonal bit (order preserved).
 __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* order,
-                                                  const unsigned long long* bits, unsigned char* accepted)
+                                                  const unsigned long long* bits, unsigned char* accepted, int* live)
 {
     extern __shared__ unsigned long long acc[];     // [words] accepted mask
     __shared__ int okflag[16];
     __shared__ unsigned conf[16];
     __shared__ int kk[16];
+    __shared__ int wcount[16];
+    __shared__ int nlive_s;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int w = tid; w < words; w += blockDim.x) acc[w] = 0ull;
     for (int k = tid; k < N; k += blockDim.x) accepted[k] = 0;
+    if (tid == 0) nlive_s = 0;
     __syncthreads();
-    for (int base = 0; base < N; base += 16) {
-        const int pos = base + wave;
+    for (int base = 0; base < N; base += 1024) {     // ordered compaction, 1024 positions per pass
+        const int pos = base + tid;
         const int k = pos < N ? order[pos] : -1;
+        const bool keep = k >= 0 && ((bits[(size_t)k * words + (k >> 6)] >> (k & 63)) & 1ull);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = nlive_s;
+        for (int v = 0; v < wave; ++v) off += wcount[v];
+        if (keep) live[off + __popcll(m & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int v = 0; v < 16; ++v) t += wcount[v]; nlive_s += t; }
+        __syncthreads();
+    }
+    __threadfence_block();
+    const int nlive = nlive_s;
+    for (int base = 0; base < nlive; base += 16) {
+        const int pos = base + wave;
+        const int k = pos < nlive ? live[pos] : -1;
         bool ok = k >= 0;
         if (k >= 0) {
             const unsigned long long* row = bits + (size_t)k * words;
@@ -318,7 +353,6 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
                 if ((row[w] & a) != a) ok = false;
             }
             ok = (__ballot(!ok) == 0ull);
-            if (!((row[k >> 6] >> (k & 63)) & 1ull)) ok = false;   // own diagonal
         }
         if (lane == 0) { okflag[wave] = ok ? 1 : 0; kk[wave] = k; }
         __syncthreads();
@@ -479,6 +513,7 @@ struct ipc_engine {
     // candidates
     double* d_cand = nullptr; int cstride = 0;
     int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
+    int* d_live = nullptr;                             // set-max: candidates with a set diagonal bit, in processing order
     std::vector<int> order, h_lo, h_hi;
     // plan / results of the last solve
     unsigned* d_counters = nullptr;   // [2*(kMaxBins+1)]
@@ -603,8 +638,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
 
 static void free_candidates(ipc_engine* h)
 {
-    hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order);
-    h->d_cand = nullptr; h->d_from = h->d_to = h->d_lo = h->d_hi = h->d_order = nullptr;
+    hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order); hipFree(h->d_live);
+    h->d_cand = nullptr; h->d_from = h->d_to = h->d_lo = h->d_hi = h->d_order = h->d_live = nullptr;
     h->N = 0;
 }
 
@@ -670,6 +705,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     HIPCHK(hipMalloc(&h->d_lo, sizeof(int) * n));
     HIPCHK(hipMalloc(&h->d_hi, sizeof(int) * n));
     HIPCHK(hipMalloc(&h->d_order, sizeof(int) * n));
+    HIPCHK(hipMalloc(&h->d_live, sizeof(int) * n));
     HIPCHK(hipMemcpy(h->d_from, from.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_to, to.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_lo, h->h_lo.data(), sizeof(int) * n, hipMemcpyHostToDevice));
@@ -918,7 +954,7 @@ extern "C" int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
-    hipLaunchKernelGGL(k_assemble, dim3((words + 63) / 64, std::min(N, 32768)), dim3(64), 0, st, N, words, world, rpr, h->d_lo,
+    hipLaunchKernelGGL(k_assemble, dim3(words, std::min((N + 255) / 256, 1024)), dim3(256), 0, st, N, words, world, rpr, h->d_lo,
                        h->d_hi, (const unsigned long long*)d_gathered, (unsigned long long*)d_bits);
     HIPCHK(hipGetLastError());
     return IPC_OK;
@@ -934,7 +970,7 @@ extern "C" int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_a
     const size_t shmem = sizeof(unsigned long long) * words;
     if (shmem > 60 * 1024) return fail(IPC_ERR_LIMIT, "ipc_set_max: N=%d exceeds the LDS-resident mask", N);
     hipLaunchKernelGGL(k_set_max, dim3(1), dim3(1024), shmem, st, N, words, h->d_order,
-                       (const unsigned long long*)d_bits, d_accepted);
+                       (const unsigned long long*)d_bits, d_accepted, h->d_live);
     HIPCHK(hipGetLastError());
     return IPC_OK;
 }
