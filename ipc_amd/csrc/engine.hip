@@ -224,6 +224,7 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
 {
     for (int i = blockIdx.y; i < N; i += gridDim.y) {
     if (i % world != rank) continue;
+    if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     int slot = -1;
     if (j < N && j >= i) {

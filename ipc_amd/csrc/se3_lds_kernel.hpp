@@ -9,9 +9,18 @@
 
 namespace ipc {
 
+// Teams per workgroup: four waves (one per SIMD, up to 512 registers each) by default.  The short-chain variants
+// (one wave per cell, M <= 3) need fewer than 256 registers and 9 - 16 KB of LDS per team, so eight teams share a CU:
+// two waves per SIMD, each hiding the other's LDS / L2 / transcendental latencies.
+#ifndef IPC_SE3_DENSE_MAXM
+#define IPC_SE3_DENSE_MAXM 1
+#endif
+template <int W, int M>
+constexpr int se3_lds_teams() { return (W == 1 && M <= IPC_SE3_DENSE_MAXM) ? 8 : 4 / W; }
+
 template <int W, int M, int NL>
-__global__ __launch_bounds__(256, 1) void se3_lds_kernel(Se3View P, const int2* cells, int ncells, unsigned* counter,
-                                                         SolveParams prm, CellOut out)
+__global__ __launch_bounds__((64 * W * se3_lds_teams<W, M>()), 1) void se3_lds_kernel(Se3View P, const int2* cells, int ncells,
+                                                                                   unsigned* counter, SolveParams prm, CellOut out)
 {
     extern __shared__ double2 dyn_lds2[];
     using T = Se3Lds<W, M, NL>;
@@ -56,14 +65,14 @@ static hipError_t launch_se3_lds_one(int n, hipStream_t st, const Se3View& P, co
                                      unsigned* counter, int n_cu)
 {
     using T = Se3Lds<W, M, NL>;
-    constexpr int kTeams = 4 / W;
+    constexpr int kTeams = se3_lds_teams<W, M>();
     constexpr size_t kBytes = kTeams * ((sizeof(T) + 15) / 16) * 16;
     static_assert(kBytes <= 160 * 1024, "team state exceeds the CU's LDS");
     auto k = se3_lds_kernel<W, M, NL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBytes);
     if (e != hipSuccess) return e;
     const int groups = std::max(1, std::min(n_cu, (n + kTeams - 1) / kTeams));
-    hipLaunchKernelGGL(k, dim3(groups), dim3(256), kBytes, st, P, cells, n, counter, prm, out);
+    hipLaunchKernelGGL(k, dim3(groups), dim3(64 * W * kTeams), kBytes, st, P, cells, n, counter, prm, out);
     return hipGetLastError();
 }
 
