@@ -218,20 +218,22 @@ __global__ void k_se3_propagate(int V, const double* rec, int stride, double* po
 // ------------------------------------------------------------------------------------------
 // planning: which cells does this rank solve, and with which kernel variant
 // ------------------------------------------------------------------------------------------
-// counts layout: [2][kMaxBins+1]  (0: diagonal cells, 1: pair cells; last slot = too long)
+// counts layout: [2][kMaxBins+1][kPlanSub]  (0: diagonal cells, 1: pair cells; last slot = too long)
+constexpr int kPlanSub = 32;
 __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world, BinCaps bc,
                        unsigned* counters, const unsigned* offsets, int2* cells, int fill)
 {
+    const int sub = (blockIdx.x + blockIdx.y) & (kPlanSub - 1);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;          // this thread's candidate, its interval read once
+    const int loj = j < N ? lo[j] : 0, hij = j < N ? hi[j] : 0;
     for (int i = blockIdx.y; i < N; i += gridDim.y) {
     if (i % world != rank) continue;
     if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     int slot = -1;
     if (j < N && j >= i) {
         const int loi = lo[i], hii = hi[i];
         if (j == i) slot = bin_of(bc, hii - loi);
         else {
-            const int loj = lo[j], hij = hi[j];
             if (min(hii, hij) - max(loi, loj) > 0)            // reference src/consensus.cpp:157-159
                 slot = (kMaxBins + 1) + bin_of(bc, max(hii, hij) - min(loi, loj));
         }
@@ -245,11 +247,13 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
         const int nsame = __popcll(same);
         const int lane = threadIdx.x & 63;
         unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&counters[sl], (unsigned)nsame);
+        // kPlanSub sub-counters per slot (chosen by block): 377 000 appends on ~20 addresses were 3.4 ms of atomics
+        const int sc = sl * kPlanSub + sub;
+        if (lane == leader) base = atomicAdd(&counters[sc], (unsigned)nsame);
         base = __shfl(base, leader, 64);
         if (slot == sl && fill) {
             const int rnk = __popcll(same & ((1ull << lane) - 1ull));
-            cells[offsets[sl] + base + rnk] = make_int2(i, j);
+            cells[offsets[sc] + base + rnk] = make_int2(i, j);
         }
         todo &= ~same;
     }
@@ -589,8 +593,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     HIPCHK(hipMalloc(&h->d_chain, sizeof(double) * (nf * (size_t)h->estride + 64)));   // + read-ahead padding
     HIPCHK(hipMalloc(&h->d_pose0, sizeof(double) * ps * (size_t)n_vertices));
-    HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1)));
-    HIPCHK(hipMalloc(&h->d_offsets, sizeof(unsigned) * 2 * (kMaxBins + 1)));
+    HIPCHK(hipMalloc(&h->d_counters, sizeof(unsigned) * 2 * (kMaxBins + 1) * kPlanSub));
+    HIPCHK(hipMalloc(&h->d_offsets, sizeof(unsigned) * 2 * (kMaxBins + 1) * kPlanSub));
     HIPCHK(hipMalloc(&h->d_wave_ctr, sizeof(unsigned) * 2 * (kMaxBins + 1)));
     {
         hipDeviceProp_t prop;
@@ -845,19 +849,28 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     constexpr int NS = 2 * (kMaxBins + 1);
     HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
     // pass 1: count
-    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS, st));
-    const dim3 pgrid((N + 255) / 256, std::min(N, 32768)), pblock(256);
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
+    const dim3 pgrid((N + 255) / 256, std::min(N, 2048)), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
     hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
                        h->d_offsets, (int2*)nullptr, 0);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
-    HIPCHK(hipMemcpyAsync(counts, h->d_counters, sizeof counts, hipMemcpyDeviceToHost, st));
+    static thread_local unsigned subcounts[NS * kPlanSub], suboffsets[NS * kPlanSub];
+    HIPCHK(hipMemcpyAsync(subcounts, h->d_counters, sizeof subcounts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int s = 0; s < NS; ++s) {
+        counts[s] = 0;
+        for (int q = 0; q < kPlanSub; ++q) counts[s] += subcounts[s * kPlanSub + q];
+    }
     // cells whose chain is longer than the largest kernel variant of the policy go through the cluster
     // solver below (one at a time, state in HBM: no length limit) instead of failing the matrix
     const unsigned n_long = counts[nb] + counts[(kMaxBins + 1) + nb];
     size_t total = 0;
     for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
+    for (int s = 0; s < NS; ++s) {                    // a slot's sub-lists are contiguous: one cell list per slot
+        unsigned o = offsets[s];
+        for (int q = 0; q < kPlanSub; ++q) { suboffsets[s * kPlanSub + q] = o; o += subcounts[s * kPlanSub + q]; }
+    }
     if (total > h->cells_cap) {
         hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
         h->d_cells = nullptr; h->d_chi = h->d_chitot = nullptr; h->d_meta = nullptr;
@@ -868,8 +881,8 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
         HIPCHK(hipMalloc(&h->d_meta, sizeof(int4) * h->cells_cap));
     }
     // pass 2: fill
-    HIPCHK(hipMemcpyAsync(h->d_offsets, offsets, sizeof offsets, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS, st));
+    HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
     hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
                        h->d_offsets, h->d_cells, 1);
     HIPCHK(hipGetLastError());
