@@ -58,7 +58,7 @@ IPC_SE3_LDS_DECL(4, 6) IPC_SE3_LDS_DECL(4, 7) IPC_SE3_LDS_DECL(4, 8) IPC_SE3_LDS
 #undef IPC_SE3_LDS_DECL
 
 // ---- wave kernels (SE2): one wave per cell, M consecutive poses per lane; capacity 64*M ----
-static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13, 15, 17};
+static const int kWaveM[] = {1, 3, 5, 7, 9, 11, 13};
 constexpr int kNumWaveM = sizeof(kWaveM) / sizeof(kWaveM[0]);
 constexpr int kWaveVariantBase = 100;         // plan variant id of the wave kernel with M poses per lane = base + M
 

@@ -95,8 +95,6 @@ hipError_t launch_se2_wave(int nl, int M, int n, hipStream_t st, const Se2View& 
         IPC_WCASE(9)
         IPC_WCASE(11)
         IPC_WCASE(13)
-        IPC_WCASE(15)
-        IPC_WCASE(17)
 #endif
         default: return hipErrorInvalidValue;
     }
