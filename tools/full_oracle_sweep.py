@@ -3,7 +3,7 @@
 decisions (max chi2 <= threshold) and max chi2.  Too long for the test suite (C2: 531 545 cells, ~13 min on the
 256-core GPU box), so it is run by hand and its summary is committed under profiles/.
 
-usage (GPU box): python tools/full_oracle_sweep.py C2 out.json [--max-seconds 1500]
+usage (GPU box): python tools/full_oracle_sweep.py C2 out.json [--max-seconds 1500] [--seed 0]
 Cells are visited in random order in chunks, so a run cut short by --max-seconds is an unbiased sample."""
 import json
 import os
@@ -28,7 +28,8 @@ def main():
     O.build()
     poses = O.propagate(g.dim, g.odom_meas)
     cores = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
+    seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
+    rng = np.random.default_rng(seed)
     order = rng.permutation(len(cells))
     th_all = np.where(cells["i"] == cells["j"], cfg.fast_reject_th, cfg.slow_reject_th)
     L = cells["hi"] - cells["lo"]
@@ -64,7 +65,7 @@ def main():
         if time.perf_counter() - t0 > max_s:
             break
     dt = time.perf_counter() - t0
-    out = dict(workload=workload, desc=desc, solved_cells=int(len(cells)), cells_compared=done,
+    out = dict(workload=workload, desc=desc, order_seed=seed, solved_cells=int(len(cells)), cells_compared=done,
                decisions_differing=diff, worst_rel_chi2_diff_converged=worst_conv,
                cells_at_iteration_cap_on_either_side=n_cap, worst_rel_chi2_diff_at_cap=worst_cap, nan_cells=n_nan,
                oracle_threads=cores, oracle_seconds=dt, oracle_cells_per_s=done / dt, first_differences=examples[:16],
