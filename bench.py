@@ -84,6 +84,13 @@ def build_workload(name):
         g = synth.inject_outliers(synth._se2_graph(2400, 40, seed=9, laps=14.0, name="long"), 200, seed=24)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=40)
         desc = "SE2 synthetic (V=2400, 40 true loops) + 200 injected outliers"
+    elif name == "T4k":       # short chains only (local loop closures, as in real odometry + place recognition): SE2 w1 / w3 bins
+        g0 = synth._se2_graph(4000, 3000, seed=13, laps=60.0, name="local")
+        span = np.abs(g0.loop_ids[:, 1] - g0.loop_ids[:, 0])
+        g0 = g0.subset(np.nonzero(span <= 140)[0])
+        g = synth.inject_outliers(g0, 3000, seed=41, local=True)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=g0.N)
+        desc = "SE2 synthetic (V=4000, %d true loops of span <= 140) + 3000 injected local outliers" % g0.N
     elif name == "tiny":
         g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)

@@ -5,14 +5,22 @@
 
 using namespace ipc;
 
-constexpr int kWavesPerGroup = 4;
+// Waves per workgroup: four (one per SIMD, up to 512 registers each); the shortest chains (M <= IPC_SE2_DENSE_MAXM
+// poses per lane) fit 256 registers, so eight of their waves share a CU -- two per SIMD, each hiding the other's
+// latencies -- and the staged chain constants.
+#ifndef IPC_SE2_DENSE_MAXM
+#define IPC_SE2_DENSE_MAXM 1
+#endif
+template <int M>
+constexpr int se2_waves() { return M <= IPC_SE2_DENSE_MAXM ? 8 : 4; }
 
 template <int M, int NL, bool STAGED>
-__global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_wave_kernel(Se2View P, const int2* cells, int ncells,
+__global__ __launch_bounds__((64 * se2_waves<M>()), 1) void se2_wave_kernel(Se2View P, const int2* cells, int ncells,
                                                                           unsigned* counter, SolveParams prm,
                                                                           CellOut out, int wlo, int wlen, int wstride)
 {
     extern __shared__ double dyn_lds[];
+    constexpr int kWavesPerGroup = se2_waves<M>();
     constexpr int kScratchDoubles = (sizeof(WaveScratch<NL>) + 7) / 8;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     WaveScratch<NL>& sh = *reinterpret_cast<WaveScratch<NL>*>(dyn_lds + wave * kScratchDoubles);
@@ -59,6 +67,7 @@ template <int M, int NL>
 static hipError_t launch_one(int n, hipStream_t st, const Se2View& P, const int2* cells, SolveParams prm, CellOut out,
                              unsigned* counter, int n_cu)
 {
+    constexpr int kWavesPerGroup = se2_waves<M>();
     const int E = P.V - 1;
     const int wstride = E + 32;                       // padding: a partially filled lane reads up to M-1 records past the end
     const size_t scratch = kWavesPerGroup * ((sizeof(WaveScratch<NL>) + 7) / 8) * sizeof(double);
