@@ -10,7 +10,7 @@ Workload (config.workload): BASELINE.json configs[1] = INTEL-like SE2 graph (V=1
 loops) + 1000 injected outliers => N=1256, 789,396 cells (i <= j).  Synthetic stand-in -- the
 INTEL file itself is not shipped with the reference and there is no network.
 
-python bench.py --gpus N --steps K --warmup W
+python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C3|C4|C4m|C5|T4k|T700|T2400]
 """
 import argparse
 import json
@@ -262,12 +262,9 @@ def main():
     for _ in range(args.warmup):
         sm.step()
     barrier()
-    solver_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sm.step()
-        if rank == 0:
-            pass
     barrier()
     dt = time.perf_counter() - t0
     # per-step solver time from HIP events recorded on the launch stream (last step)
