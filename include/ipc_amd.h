@@ -196,6 +196,14 @@ int ipc_current_poses(ipc_engine_t* h, double* poses_out);
 int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int iterations, double* poses_out,
                        ipc_check_info_t* info);
 
+/* ---- diagnostics of the incremental mode's dense solver (tests only) ---------------------------------
+ * Solves the SPD system the cluster solve factors per dog-leg iteration (the capacitance matrix of the accepted
+ * loops).  system: (n+1) x n column major, lower triangle of S in rows 0..n-1, right-hand side in row n.
+ * mode 0: one launch per block column (host-driven solver); mode 1: the orchestration inside the persistent
+ * cluster kernel, on `workgroups` workgroups.  Both must return the same bits.  info: 0, or 1 + the first block
+ * column with a non-positive pivot. */
+int ipc_debug_dense_solve(int n, const double* system, int mode, int workgroups, double* x_out, int* info_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
+    "ipc_debug_dense_solve",
 ]
 
 
@@ -97,6 +98,7 @@ def load():
     lib.ipc_add_to_consensus.argtypes = [vp, ip]
     lib.ipc_current_poses.argtypes = [vp, vp]
     lib.ipc_final_optimize.argtypes = [vp, vp, ip, vp, C.POINTER(CheckInfo)]
+    lib.ipc_debug_dense_solve.argtypes = [ip, vp, ip, ip, vp, C.POINTER(ip)]
     assert C.sizeof(CellInfo) == CELL_DTYPE.itemsize
     _lib = lib
     return lib

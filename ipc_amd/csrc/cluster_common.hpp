@@ -19,6 +19,13 @@ namespace ipc {
 
 constexpr int kGB = 256;                     // threads per block of the grid kernels
 
+// Loads / stores of data that ANOTHER workgroup writes / reads inside one launch (the persistent cluster
+// kernel, cluster_persist.hpp): agent-scope relaxed atomics = global_load / global_store ... sc1, which bypass the
+// CU's L1 and write through the XCD's L2 (per-XCD L2s are not coherent with each other), so that no cache
+// write-back / invalidate is needed around the grid barriers.  In the one-kernel-per-phase path they cost nothing.
+__device__ __forceinline__ double ld_shared(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_shared(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int K>
 __device__ __forceinline__ void gk_block_reduce_store(double (&v)[K], double* partial_row)
 {

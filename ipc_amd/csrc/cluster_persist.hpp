@@ -1,0 +1,849 @@
+// Device-resident cluster solve: the whole dog-leg of one cluster problem (IPC::agreementCheck's
+// isAgreeingWithCurrentState, reference src/consensus_utils.cpp:7-22, or the final map,
+// src/simulation.cpp:50-65) in ONE persistent launch, no host round trip until the result record is written.
+//
+// Same arithmetic as the one-kernel-per-phase solvers (cluster_se2.hpp / cluster_se3.hpp, whose per-index bodies
+// `gk*_at` it calls, and dense_chol.hpp, whose factorisation it re-orchestrates): the reductions add in the same
+// order, so the two paths agree bit for bit -- tests/test_gpu_persistent.py holds them against each other.
+//
+//   workgroup 0 ("leader", 512 threads) runs the dog-leg control flow (g2o OptimizationAlgorithmDogleg::solve as
+//     restated in cluster_common.hpp::cluster_dogleg) and every chain phase: a phase is a loop over the poses /
+//     loops followed by __syncthreads(), its scalars are reduced in LDS -- no launch, no barrier across CUs;
+//   workgroups 1 .. G-1 ("helpers") sleep on a grid barrier until the leader asks for a factorisation, then share
+//     the assembly of the capacitance matrix and its blocked Cholesky (64 x 64 tiles, two per workgroup at a
+//     time).  The leader runs the critical path of the factorisation one step ahead: while the helpers apply block
+//     column k to the trailing matrix, it brings the next diagonal block up to date itself and factors it, so the
+//     32 dependent pivots of a block column never wait for the bulk update.
+//
+// Data that crosses workgroups inside the launch (capacitance matrix, factor, pivots) moves with sc1 loads / stores
+// (ld_shared / st_shared) and needs no cache maintenance; the leader's chain arrays that the assembly reads (prefix
+// sums, Gamma_l, loop errors) are published once per iteration with an agent-scope release / acquire pair.
+// G is sized by the capacitance system (1 for systems of one tile: then there is no cross-workgroup traffic at all).
+#pragma once
+#include "cluster_se2.hpp"
+#include "cluster_se3.hpp"
+
+namespace ipc {
+
+constexpr int kPT = 512;                     // threads per workgroup (256 VGPRs per thread: the tile update and the SE3 phases need them)
+constexpr int kPSG = kPT / 256;              // 256-thread sub-groups (one 64 x 64 tile each)
+constexpr unsigned kSpinLimit = 1u << 23;    // polls before a barrier gives up (seconds): a lost workgroup must not hang the GPU
+
+struct PersistCtl {                          // device memory, zeroed before every launch
+    unsigned bar;                            // grid barrier: monotonic arrival counter
+    int cmd;                                 // leader -> helpers: 1 = factor, 2 = exit
+    int le_sel;                              // 1: the committed loop errors sit in the second buffer (commit swaps them)
+    int error;                               // 1: a barrier timed out
+};
+
+struct PersistOut {                          // result record (device, copied to pinned host memory behind the kernel)
+    double max_chi2, chi2_total, chi2_initial;
+    int iterations, tries, flags, evals;
+    int x_sel;                               // 1: the optimised poses sit in the second pose buffer
+    int error, pad0, pad1;
+};
+
+struct PersistArgs {
+    const double* src; int src_ld;           // committed poses of the whole trajectory (global indexing)
+    int iterations; double term_eps;
+    PersistCtl* ctl; PersistOut* out;
+    double* dinv;                            // [n] reciprocal pivots of the factor
+};
+
+// ---- LDS carve-up (doubles) -------------------------------------------------------------------------------
+constexpr int kLdsD = 0;                                   // [32][33] diagonal block of the current block column
+constexpr int kLdsDinv = kCB * (kCB + 1);                  // [32]
+constexpr int kLdsR = kLdsDinv + kCB;                      // phase-private region
+constexpr int kLdsPanel = kCB * (64 + 1);                  // one [32][65] panel
+constexpr int kLdsTotal = kLdsR + kPSG * 2 * kLdsPanel;    // 17 728 doubles = 141 824 bytes
+// leader's use of the region: reduction staging [kPSG][2][256], results [8], scan partials [9][16]
+constexpr int kLdsRed = kLdsR, kLdsRes = kLdsRed + kPSG * 2 * 256, kLdsWsum = kLdsRes + 8, kLdsMisc = kLdsWsum + 9 * 16;
+static_assert(kLdsMisc + 64 <= kLdsTotal, "LDS carve-up");
+
+struct GridBar { unsigned* ctr; unsigned target; int G; int* error; };
+
+// Every workgroup arrives once; leaves when all G have.  Monotonic counter, relaxed sc1 poll with s_sleep.  The
+// caller's cross-workgroup stores are sc1 (write-through) and are drained by the s_waitcnt before the arrival.
+__device__ __forceinline__ bool grid_barrier(GridBar& gb)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (gb.G == 1) return true;
+    gb.target += (unsigned)gb.G;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(gb.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(gb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { __hip_atomic_store(gb.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(gb.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+// ---- leader phases ----------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void lead_for(int n, F f)
+{
+    for (int i = threadIdx.x; i < n; i += kPT) f(i);
+    __syncthreads();
+}
+
+// Sum of K per-index values over indices 0 .. nblk*256-1, added exactly as gk_block_reduce_store + gk_sum add them:
+// a binary tree inside each run of 256 indices, then the runs in ascending order.
+template <int K, class F>
+__device__ __forceinline__ void lead_reduce(int nblk, double* lds, double (&tot)[K], F f)
+{
+    double* red = lds + kLdsRed;
+    double* res = lds + kLdsRes;
+    const int tid = threadIdx.x, q = tid >> 8, t = tid & 255;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (int vb0 = 0; vb0 < nblk; vb0 += kPSG) {
+        const int vb = vb0 + q;
+        double v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = 0.0;
+        if (vb < nblk) f(vb * 256 + t, v);
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[(q * K + k) * 256 + t] = v[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (t < s) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[(q * K + k) * 256 + t] += red[(q * K + k) * 256 + t + s];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int qq = 0; qq < kPSG && vb0 + qq < nblk; ++qq) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] += red[(qq * K + k) * 256];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) res[k] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = res[k];
+    __syncthreads();
+}
+
+// In-place inclusive prefix sums over indices 1..L of K arrays (row length ld), added as gk_scan adds them: runs of
+// 1024 indices = 16 wave scans whose totals are added in wave order (here: kPT / 64 waves, 1024 / kPT passes per run).
+template <int K>
+__device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* lds)
+{
+    constexpr int NP = 1024 / kPT, NW = kPT / 64;
+    double* wsum = lds + kLdsWsum;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double carry[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) carry[k] = 0.0;
+    for (int base = 1; base <= L; base += 1024) {
+        double v[NP][K];
+#pragma unroll
+        for (int hp = 0; hp < NP; ++hp) {
+            const int i = base + hp * kPT + tid;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                v[hp][k] = i <= L ? arr[(size_t)k * ld + i] : 0.0;
+                v[hp][k] = wave_inclusive_scan(v[hp][k]);
+                if (lane == 63) wsum[k * 16 + hp * NW + wave] = v[hp][k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double tt = carry[k];
+            for (int w = 0; w < 16; ++w) tt += wsum[k * 16 + w];
+#pragma unroll
+            for (int hp = 0; hp < NP; ++hp) {
+                const int i = base + hp * kPT + tid, vw = hp * NW + wave;
+                double off = carry[k];
+                for (int w = 0; w < vw; ++w) off += wsum[k * 16 + w];
+                if (i <= L) arr[(size_t)k * ld + i] = v[hp][k] + off;
+            }
+            carry[k] = tt;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void lead_scan(double* arr, int K, int L, int ld, double* lds)
+{
+    while (K >= 9) { lead_scan_k<9>(arr, L, ld, lds); arr += 9 * (size_t)ld; K -= 9; }
+    while (K >= 3) { lead_scan_k<3>(arr, L, ld, lds); arr += 3 * (size_t)ld; K -= 3; }
+    while (K >= 1) { lead_scan_k<1>(arr, L, ld, lds); arr += (size_t)ld; K -= 1; }
+}
+
+// ---- blocked Cholesky across the workgroups of the launch (dense_chol.hpp's arithmetic) ---------------------
+// first wave: factor the 32 x 32 block in Dn (identity padded), reciprocal pivots to Dninv; false on a non-positive pivot
+__device__ __noinline__ bool potrf32_wave(double (*Dn)[kCB + 1], double* Dninv)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31;
+    bool ok = true;
+    double row[kCB];
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) row[c] = Dn[r][c];
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) {
+        const double piv = read_lane(row[c], c);
+        if (!(piv > 0)) ok = false;
+        const double inv = rsqrt_newton(piv);
+        const double lrc = r == c ? piv * inv : (r > c ? row[c] * inv : 0.0);
+        row[c] = lrc;
+        if (lane == c) Dninv[c] = inv;
+#pragma unroll
+        for (int cc = c + 1; cc < kCB; ++cc) {
+            const double lcc = read_lane(lrc, cc);
+            row[cc] = fma(-lrc, lcc, row[cc]);
+        }
+    }
+    if (lane < kCB) {
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) Dn[r][c] = row[c];
+    }
+    return ok;
+}
+
+// whole workgroup: write the factored block Dn / Dninv of block column kb0 (width nbb) to the factor
+__device__ __forceinline__ void publish_block(double (*Dn)[kCB + 1], const double* Dninv, double* Lf, double* dinv, int ld, int kb0, int nbb)
+{
+    for (int idx = threadIdx.x; idx < kCB * kCB; idx += kPT) {
+        const int r = idx % kCB, c = idx / kCB;
+        if (r < nbb && c < nbb && r >= c) st_shared(&Lf[(size_t)(kb0 + c) * ld + kb0 + r], Dn[r][c]);
+    }
+    if (threadIdx.x < nbb) st_shared(&dinv[kb0 + threadIdx.x], Dninv[threadIdx.x]);
+}
+
+// One 64 x 64 tile (bx >= by) of the trailing update of block column k0, by one 256-thread sub-group; the two
+// __syncthreads() are workgroup-wide, so every sub-group of the workgroup calls this the same number of times
+// (has = false: no tile this round).  D / Dinv: the factored diagonal block of the column, in LDS.
+// skip_next_diag: leave rows / columns k1 .. k1+32 (the next diagonal block, inside tile (0, 0)) untouched.
+__device__ __noinline__ void chol_tile(double* A, double* Lf, int n, int ld, int k0, int nb, bool has, int bx, int by,
+                                          double (*D)[kCB + 1], const double* Dinv, double* panel, bool skip_next_diag)
+{
+    const int t = threadIdx.x & 255, wv = t >> 6, lane = t & 63;
+    const int k1 = k0 + nb;
+    const int i0 = k1 + bx * 64, j0 = k1 + by * 64;
+    double (*Ai)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel);
+    double (*Aj)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel + kLdsPanel);
+    if (has && wv < 2) {
+        double x[kCB];
+        const int prow = wv == 0 ? i0 + lane : j0 + lane;
+        const bool pvalid = wv == 0 ? prow <= n : prow < n;           // row n (rhs) only ever is a tile ROW
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? ld_shared(&A[(size_t)(k0 + c) * ld + prow]) : 0.0;
+        double (*P)[64 + 1] = wv == 0 ? Ai : Aj;
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) {
+            double v = x[c];
+#pragma unroll
+            for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
+            x[c] = v * Dinv[c];
+            P[c][lane] = c < nb ? x[c] : 0.0;
+            if (wv == 0 && by == 0 && c < nb && pvalid) st_shared(&Lf[(size_t)(k0 + c) * ld + prow], x[c]);
+        }
+    }
+    __syncthreads();
+    if (has && j0 < n) {
+        const int tx = t & 15, ty = t >> 4;
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < kCB; ++p) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = Ai[p][tx + 16 * q]; bv[q] = Aj[p][ty + 16 * q]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + ty + 16 * b;
+            if (j >= n) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + tx + 16 * a;
+                // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
+                if (skip_next_diag && i < min(k1 + kCB, n)) continue;       // (row n is the right-hand side, never part of it)
+                if (i <= n && i >= j) {
+                    double* p = &A[(size_t)j * ld + i];
+                    st_shared(p, ld_shared(p) - acc[a][b]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Factor the (n+1) x n system A (row n = right-hand side) into Lf / dinv; all G workgroups call it together.
+// Returns (on workgroup 0) 0 or 1 + the first block column with a non-positive pivot.
+__device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, int n, GridBar& gb, double* lds, bool& alive)
+{
+    const int ld = n + 1, g = blockIdx.x, G = gb.G, tid = threadIdx.x, sg = tid >> 8;
+    double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
+    double* Dinv = lds + kLdsDinv;
+    // workgroup 0's private blocks: panel rows of the next diagonal block, the block itself, its reciprocal pivots
+    double (*Lrow)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR);
+    double (*Dn)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR + kCB * (kCB + 1));
+    double* Dninv = lds + kLdsR + 2 * kCB * (kCB + 1);
+    int info = 0;
+    if (g == 0) {                                             // diagonal block 0 straight from the system
+        const int nb0 = min(kCB, n);
+        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+            const int r = idx % kCB, c = idx / kCB;
+            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[(size_t)c * ld + r]) : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        bool ok = true;
+        if (tid < 64) ok = potrf32_wave(Dn, Dninv);
+        if (tid == 0 && !ok) lds[kLdsMisc] = 1.0; else if (tid == 0) lds[kLdsMisc] = 0.0;
+        __syncthreads();
+        if (lds[kLdsMisc] != 0.0) info = 1;
+        publish_block(Dn, Dninv, Lf, dinv, ld, 0, nb0);
+    }
+    alive = grid_barrier(gb);
+    for (int k0 = 0; k0 < n && alive; k0 += kCB) {
+        const int nb = min(kCB, n - k0), k1 = k0 + nb;
+        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+            const int r = idx % kCB, c = idx / kCB;
+            D[r][c] = (r < nb && c < nb && r >= c) ? ld_shared(&Lf[(size_t)(k0 + c) * ld + k0 + r]) : (r == c ? 1.0 : 0.0);
+        }
+        if (tid < kCB) Dinv[tid] = tid < nb ? ld_shared(&dinv[k0 + tid]) : 1.0;
+        __syncthreads();
+        const bool tiles_here = G == 1 || g > 0;
+        if (tiles_here) {
+            const int nti = (n + 1 - k1 + 63) / 64, ntj = max((n - k1 + 63) / 64, 1);
+            int total = 0;
+            for (int by = 0; by < ntj; ++by) total += max(nti - by, 0);
+            const int nslots = G == 1 ? kPSG : kPSG * (G - 1);
+            const int slot = G == 1 ? sg : kPSG * (g - 1) + sg;
+            for (int base = 0; base < total; base += nslots) {
+                const int tt = base + slot;
+                const bool has = tt < total;
+                int by = 0, rem = tt;
+                if (has) { while (rem >= nti - by) { rem -= nti - by; ++by; } }
+                chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, D, Dinv, lds + kLdsR + sg * 2 * kLdsPanel,
+                          G > 1 && has && by == 0 && rem == 0);
+            }
+        }
+        if (g == 0 && k1 < n) {
+            const int nb2 = min(kCB, n - k1);
+            if (G == 1) {                                     // the tiles above have updated the block in A
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+                    const int r = idx % kCB, c = idx / kCB;
+                    Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[(size_t)(k1 + c) * ld + k1 + r]) : (r == c ? 1.0 : 0.0);
+                }
+            } else {
+                // one step ahead of the helpers: rows k1 .. k1+nb2 of block column k0 against D, then the update of
+                // the next diagonal block with them -- the same operations, in the same order, as chol_tile applies
+                if (tid < 64) {
+                    const int lane = tid, prow = k1 + lane;
+                    const bool pvalid = lane < nb2;
+                    double x[kCB];
+#pragma unroll
+                    for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? ld_shared(&A[(size_t)(k0 + c) * ld + prow]) : 0.0;
+#pragma unroll
+                    for (int c = 0; c < kCB; ++c) {
+                        double v = x[c];
+#pragma unroll
+                        for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
+                        x[c] = v * Dinv[c];
+                        if (lane < kCB) Lrow[c][lane] = c < nb ? x[c] : 0.0;
+                    }
+                }
+                __syncthreads();
+                for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+                    const int r = idx >> 5, s = idx & 31;
+                    double val = r == s ? 1.0 : 0.0;
+                    if (r < nb2 && s < nb2 && s <= r) {
+                        double acc = 0.0;
+#pragma unroll 8
+                        for (int p = 0; p < kCB; ++p) acc = fma(Lrow[p][r], Lrow[p][s], acc);
+                        val = ld_shared(&A[(size_t)(k1 + s) * ld + k1 + r]) - acc;
+                    }
+                    Dn[r][s] = val;
+                }
+            }
+            __syncthreads();
+            bool ok = true;
+            if (tid < 64) ok = potrf32_wave(Dn, Dninv);
+            if (tid == 0) lds[kLdsMisc] = ok ? 0.0 : 1.0;
+            __syncthreads();
+            if (lds[kLdsMisc] != 0.0 && info == 0) info = k1 + 1;
+            publish_block(Dn, Dninv, Lf, dinv, ld, k1, nb2);
+        }
+        alive = grid_barrier(gb);
+    }
+    return info;
+}
+
+// L^T x = y (y = row n of the factor), workgroup 0 only: dense_chol.hpp::chol_backsolve with sc1 reads
+__device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x, double* lds)
+{
+    double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
+    double* t = lds + kLdsDinv;
+    const int ld = n + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nblk = (n + kCB - 1) / kCB;
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
+        for (int c = wave; c < nb; c += kPT / 64) {
+            double acc = 0.0;
+            for (int r = k1 + lane; r < n; r += 64) acc += ld_shared(&Lf[(size_t)(k0 + c) * ld + r]) * x[r];
+            acc = wave_sum(acc);
+            if (lane == 0) t[c] = acc;
+        }
+        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+            const int r = idx % kCB, c = idx / kCB;
+            D[r][c] = (r < nb && c < nb && r >= c) ? ld_shared(&Lf[(size_t)(k0 + c) * ld + k0 + r]) : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int l = lane & 31;
+            double v = l < nb ? ld_shared(&Lf[(size_t)(k0 + l) * ld + n]) - t[l] : 0.0;
+            const double dinv = 1.0 / D[l][l];
+            double col[kCB];
+#pragma unroll
+            for (int r = 0; r < kCB; ++r) col[r] = D[r][l];
+#pragma unroll
+            for (int r = kCB - 1; r >= 0; --r) {
+                const double xr = read_lane(v, r) * read_lane(dinv, r);
+                v = l == r ? xr : (l < r ? fma(-col[r], xr, v) : v);
+            }
+            if (lane < nb) x[k0 + lane] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// The factorisation + back substitution alone (ipc_debug_dense_solve: parity of the persistent orchestration with
+// dense_chol.hpp::chol_solve_device on arbitrary systems)
+__global__ __launch_bounds__(kPT, 1) void pchol_test_kernel(double* A, double* Lf, double* dinv, int n, double* x, PersistCtl* ctl, int* info)
+{
+    extern __shared__ double lds[];
+    GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error};
+    bool alive = true;
+    const int r = pchol_factor(A, Lf, dinv, n, gb, lds, alive);
+    if (blockIdx.x == 0) {
+        pchol_backsolve(Lf, n, x, lds);
+        if (threadIdx.x == 0) *info = alive ? r : -1;
+    }
+}
+
+// ---- pose-type bindings -------------------------------------------------------------------------------------
+struct PersistSe2 {
+    using Dev = ClusterDev;
+    static constexpr int kD = 3, kNPS = 9, kNND = 3, kSC1 = 1, kSC2 = 2;
+    static constexpr int kEdgeDoubles = 43, kLoopDoubles = 27;          // per ld / per loop, + (ld + nl) of chi_edges
+    __device__ static void load_initial(const Dev& D, const double* src, int V, int i)
+    {
+        const size_t s = (size_t)D.lo + i;
+        D.X.x[i] = src[s]; D.X.y[i] = src[(size_t)V + s]; D.X.th[i] = src[2 * (size_t)V + s];
+        D.X.c[i] = src[3 * (size_t)V + s]; D.X.s[i] = src[4 * (size_t)V + s];
+    }
+    __device__ static void eval(const Dev& D, bool trial, int i, double (&v)[1])
+    {
+        if (trial) gk_eval_at(D, D.Xn, D.en, D.len, i, v); else gk_eval_at(D, D.X, D.e, D.le, i, v);
+    }
+    __device__ static void chi_edges(const Dev& D, int i) { gk_chi_edges_at(D, i); }
+    __device__ static void force(const Dev& D, int i) { gk_force_at(D, i); }
+    __device__ static void b(const Dev& D, int i, double (&v)[1]) { gk_b_at(D, i, v); }
+    __device__ static void bHb_psi(const Dev& D, int i, double (&v)[1]) { gk_bHb_psi_at(D, i, v); }
+    __device__ static void assemble(const Dev& D, int l1, int l2) { gk_assemble_at(D, l1, l2); }
+    __device__ static void nu(const Dev& D, int l) { gk_nu_at(D, l); }
+    __device__ static void events(const Dev& D, int j) { gk_events_at(D, j); }
+    __device__ static void rho(const Dev& D, int i) { gk_rho_at(D, i); }
+    __device__ static void term(const Dev& D, int i) { gk_term_at(D, i); }
+    __device__ static void h(const Dev& D, int i, double (&v)[2]) { gk_h_at(D, i, v); }
+    __device__ static void blend(const Dev& D, double alpha, int i, double (&v)[2]) { gk_blend_at(D, alpha, i, v); }
+    __device__ static void update(const Dev& D, double p, double q, int i, double (&v)[1]) { gk_update_at(D, p, q, i, v); }
+    static void exchange(Dev& D)                 // the view after a commit: committed <-> trial buffers
+    {
+        PoseArr tx = D.X; D.X = D.Xn; D.Xn = tx;
+        double* t = D.e; D.e = D.en; D.en = t;
+        t = D.le; D.le = D.len; D.len = t;
+    }
+    static void carve(Dev& D, double* edge, double* loop, int ld, int nl)
+    {
+        double* p = edge;
+        auto take = [&](size_t n) { double* q = p; p += n; return q; };
+        D.X = PoseArr{take(ld), take(ld), take(ld), take(ld), take(ld)};
+        D.Xn = PoseArr{take(ld), take(ld), take(ld), take(ld), take(ld)};
+        D.e = take(3 * (size_t)ld); D.en = take(3 * (size_t)ld); D.g = take(3 * (size_t)ld); D.m = take(3 * (size_t)ld);
+        D.b = take(3 * (size_t)ld); D.h = take(3 * (size_t)ld); D.ps = take(9 * (size_t)ld); D.nd = take(3 * (size_t)ld);
+        D.sc = take(3 * (size_t)ld);
+        D.chi_edges = take((size_t)ld + nl);
+        double* q = loop;
+        auto takel = [&](size_t n) { double* r = q; q += n; return r; };
+        D.le = takel(3 * (size_t)nl); D.len = takel(3 * (size_t)nl); D.lg = takel(3 * (size_t)nl); D.lm = takel(3 * (size_t)nl);
+        D.gam = takel(9 * (size_t)nl); D.nu = takel(3 * (size_t)nl); D.rhs = takel(3 * (size_t)nl);
+    }
+};
+
+struct PersistSe3 {
+    using Dev = ClusterDev3;
+    static constexpr int kD = 6, kNPS = 27, kNND = 6, kSC1 = 3, kSC2 = 3;
+    static constexpr int kEdgeDoubles = 99, kLoopDoubles = 72;
+    __device__ static void load_initial(const Dev& D, const double* src, int src_ld, int i)
+    {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) D.X[(size_t)k * D.ld + i] = src[(size_t)k * src_ld + D.lo + i];
+    }
+    __device__ static void eval(const Dev& D, bool trial, int i, double (&v)[1])
+    {
+        if (trial) gk3_eval_at(D, D.Xn, D.en, D.len, i, v); else gk3_eval_at(D, D.X, D.e, D.le, i, v);
+    }
+    __device__ static void chi_edges(const Dev& D, int i) { gk3_chi_edges_at(D, i); }
+    __device__ static void force(const Dev& D, int i) { gk3_force_at(D, i); }
+    __device__ static void b(const Dev& D, int i, double (&v)[1]) { gk3_b_at(D, i, v); }
+    __device__ static void bHb_psi(const Dev& D, int i, double (&v)[1]) { gk3_bHb_psi_at(D, i, v); }
+    __device__ static void assemble(const Dev& D, int l1, int l2) { gk3_assemble_at(D, l1, l2); }
+    __device__ static void nu(const Dev& D, int l) { gk3_nu_at(D, l); }
+    __device__ static void events(const Dev& D, int j) { gk3_events_at(D, j); }
+    __device__ static void rho(const Dev& D, int i) { gk3_rho_at(D, i); }
+    __device__ static void term(const Dev& D, int i) { gk3_term_at(D, i); }
+    __device__ static void h(const Dev& D, int i, double (&v)[2]) { gk3_h_at(D, i, v); }
+    __device__ static void blend(const Dev& D, double alpha, int i, double (&v)[2]) { gk3_blend_at(D, alpha, i, v); }
+    __device__ static void update(const Dev& D, double p, double q, int i, double (&v)[1]) { gk3_update_at(D, p, q, i, v); }
+    static void exchange(Dev& D)                 // the view after a commit: committed <-> trial buffers
+    {
+        double* t = D.X; D.X = D.Xn; D.Xn = t;
+        t = D.e; D.e = D.en; D.en = t;
+        t = D.le; D.le = D.len; D.len = t;
+    }
+    static void carve(Dev& D, double* edge, double* loop, int ld, int nl)
+    {
+        double* p = edge;
+        auto take = [&](size_t n) { double* q = p; p += n; return q; };
+        D.X = take(12 * (size_t)ld); D.Xn = take(12 * (size_t)ld);
+        D.e = take(6 * (size_t)ld); D.en = take(6 * (size_t)ld); D.g = take(6 * (size_t)ld); D.m = take(6 * (size_t)ld);
+        D.b = take(6 * (size_t)ld); D.h = take(6 * (size_t)ld); D.ps = take(27 * (size_t)ld);
+        D.nd = take(6 * (size_t)ld); D.sc = take(6 * (size_t)ld);
+        D.chi_edges = take((size_t)ld + nl);
+        double* q = loop;
+        auto takel = [&](size_t n) { double* r = q; q += n; return r; };
+        D.le = takel(6 * (size_t)nl); D.len = takel(6 * (size_t)nl); D.lg = takel(6 * (size_t)nl); D.lm = takel(6 * (size_t)nl);
+        D.gam = takel(36 * (size_t)nl); D.nu = takel(6 * (size_t)nl); D.rhs = takel(6 * (size_t)nl);
+    }
+};
+
+// ---- the kernel ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev D0, typename T::Dev D1, PersistArgs P)
+{
+    // D0: the problem as carved by the host; D1: the same with the committed / trial buffers exchanged (a commit of
+    // the dog-leg is a switch between the two views, both stay in the kernel-argument segment)
+    const typename T::Dev* Dp = &D0;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error};
+    const int L = Dp->L, nl = Dp->nl, ld = Dp->ld;
+    const int n = T::kD * nl;
+    double* A = Dp->S;
+    double* Lf = Dp->S + (size_t)(n + 1) * n;
+    bool alive = true;
+
+    auto assemble_share = [&](const typename T::Dev& Dv) {
+        const long total = (long)nl * nl;
+        for (long q = (long)g * kPT + tid; q < total; q += (long)G * kPT) {
+            const int l1 = (int)(q / nl), l2 = (int)(q - (long)l1 * nl);
+            if (l2 <= l1) T::assemble(Dv, l1, l2);
+        }
+    };
+
+    if (g != 0) {                                             // ---- helpers ----
+        for (;;) {
+            if (!grid_barrier(gb)) return;                                                   // B1: a command is posted
+            if (__hip_atomic_load(&P.ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) return;
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // the leader's ps / Gamma / loop errors
+            __syncthreads();
+            assemble_share(__hip_atomic_load(&P.ctl->le_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? D1 : D0);
+            if (!grid_barrier(gb)) return;                                                   // B2: the system is assembled
+            pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
+            if (!alive) return;
+        }
+    }
+
+    // ---- leader ----
+    const int nidx = L + nl + 1, nblk = (nidx + 255) / 256;
+    int n_commit = 0;
+    lead_for(L + 1, [&](int i) { T::load_initial((*Dp), P.src, P.src_ld, i); });
+
+    auto evaluate = [&](bool trial) {
+        double tot[1];
+        lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::eval((*Dp), trial, i, v); });
+        return tot[0];
+    };
+    // H h_gn = b through the capacitance system; returns the solver's info word
+    auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
+        lead_for(nidx, [&](int i) { T::force((*Dp), i); });
+        { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::b((*Dp), i, v); }); bb = tot[0]; }
+        { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::bHb_psi((*Dp), i, v); }); bHb = tot[0]; }
+        lead_scan(Dp->ps, T::kNPS, L, ld, lds);
+        // hand the assembly's inputs to the helpers, factor together
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (G > 1 && tid == 0) {
+            __hip_atomic_store(&P.ctl->le_sel, n_commit & 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P.ctl->cmd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        alive = grid_barrier(gb);                                                            // B1
+        assemble_share((*Dp));
+        if (alive) alive = grid_barrier(gb);                                                 // B2
+        int info = 0;
+        if (alive) info = pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
+        pchol_backsolve(Lf, n, Dp->rhs, lds);
+        lead_for(nl, [&](int l) { T::nu((*Dp), l); });
+        lead_for(L + 2, [&](int j) { T::events((*Dp), j); });
+        lead_scan(Dp->nd, T::kNND, L, ld, lds);
+        lead_for(nidx, [&](int i) { T::rho((*Dp), i); });
+        lead_scan(Dp->sc, T::kSC1, L, ld, lds);
+        lead_for(nidx, [&](int i) { T::term((*Dp), i); });
+        lead_scan(Dp->sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds);
+        { double tot[2]; lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::h((*Dp), i, v); }); hh = tot[0]; bh = tot[1]; }
+        return info;
+    };
+
+    // g2o OptimizationAlgorithmDogleg::solve / SparseOptimizer::optimize, as cluster_dogleg() runs it from the host.
+    // The scalar control arithmetic is kept unfused: cluster_dogleg() computes it on the CPU (x86-64, no FMA).
+    PersistOut o{};
+    double currentChi = evaluate(false);
+    o.chi2_initial = currentChi;
+    {
+#pragma clang fp contract(off)
+    double delta = 1e4;
+    const int maxTrials = 100;
+    const int n_edges = L + nl;
+    bool lastGN = false;
+    for (int it = 0; it < P.iterations && alive; ++it) {
+        double bb, bHb, hh, bh;
+        const int info = linearize(bb, bHb, hh, bh);
+        if (!alive) break;
+        if (info != 0) { o.flags |= 2; o.iterations = it + 1; break; }
+        const double hHh = bh;
+        const double alpha = bb / bHb, hsdNorm = sqrt(alpha * alpha * bb), hgnNorm = sqrt(hh);
+        if (lastGN && hgnNorm < delta && fabs(bh) * n_edges < P.term_eps * currentChi) {
+            o.iterations = it + 1; o.tries += maxTrials; o.flags |= 1;
+            break;
+        }
+        const double deltaAtEntry = delta;
+        bool goodStep = false;
+        int numTries = 0;
+        do {
+            ++numTries;
+            int stepType;
+            double beta = 0.0, sdScale = 0.0;
+            if (hgnNorm < delta) stepType = 0;
+            else if (hsdNorm > delta) { stepType = 1; sdScale = delta / hsdNorm; }
+            else {
+                stepType = 2;
+                double tot[2];
+                lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::blend((*Dp), alpha, i, v); });
+                const double c = tot[0], bma = tot[1];
+                const double hsdSq = alpha * alpha * bb;
+                if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
+                else beta = (delta * delta - hsdSq) / (c + sqrt(c * c + bma * (delta * delta - hsdSq)));
+            }
+            double pcoef, qcoef, hdlNorm;
+            if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
+            else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
+            else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double bhdl = pcoef * bb + qcoef * bh;
+            double linearGain = -1 * hdlHhdl + 2 * bhdl;
+            double changed[1];
+            lead_reduce<1>(nblk, lds, changed, [&](int i, double (&v)[1]) { T::update((*Dp), pcoef, qcoef, i, v); });
+            const bool anyChanged = changed[0] != 0.0;
+            const double newChi = evaluate(true);
+            ++o.evals;
+            const double nonLinearGain = currentChi - newChi;
+            if (fabs(linearGain) < 1e-12) linearGain = 1e-12;
+            const double rho = nonLinearGain / linearGain;
+            if (rho > 0) {
+                goodStep = true;
+                currentChi = newChi;
+                ++n_commit;
+                Dp = (n_commit & 1) ? &D1 : &D0;
+            }
+            if (rho > 0.75) delta = fmax(delta, 3 * hdlNorm);
+            else if (rho < 0.25) delta *= 0.5;
+            if (!goodStep) {
+                if (rho != rho) {
+                    numTries = maxTrials;
+                } else if (stepType == 0) {
+                    while (numTries < maxTrials && hgnNorm < delta) { ++numTries; delta *= 0.5; }
+                } else if (stepType == 1 && !anyChanged) {
+                    numTries = maxTrials;
+                }
+            }
+        } while (!goodStep && numTries < maxTrials);
+        lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
+        o.iterations = it + 1;
+        o.tries += numTries;
+        if (numTries == maxTrials || !goodStep) { o.flags |= 1; break; }
+    }
+    }
+    // release the helpers
+    if (G > 1) {
+        if (tid == 0) __hip_atomic_store(&P.ctl->cmd, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        grid_barrier(gb);
+    }
+    // per-edge chi2 of the committed state and their maximum (a NaN makes the maximum NaN: `chi2 > th` is then false)
+    lead_for(nidx, [&](int i) { T::chi_edges((*Dp), i); });
+    {
+        double mx = 0.0;
+        bool nan = false;
+        for (int i = tid; i < L + nl; i += kPT) {
+            const double c = Dp->chi_edges[i];
+            if (c != c) nan = true; else mx = fmax(mx, c);
+        }
+        mx = wave_max(mx);
+        const bool wnan = __any(nan);
+        double* red = lds + kLdsRed;
+        if ((tid & 63) == 0) { red[tid >> 6] = mx; red[16 + (tid >> 6)] = wnan ? 1.0 : 0.0; }
+        __syncthreads();
+        if (tid == 0) {
+            double m = 0.0, f = 0.0;
+            for (int w = 0; w < kPT / 64; ++w) { m = fmax(m, red[w]); f += red[16 + w]; }
+            o.max_chi2 = f != 0.0 ? __builtin_nan("") : m;
+            o.chi2_total = currentChi;
+            o.x_sel = n_commit & 1;
+            o.error = alive ? 0 : 1;
+            *P.out = o;
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+// One solver instance = one set of workspaces + one pinned result record; launch() enqueues a solve on a stream and
+// returns, wait() blocks for its record.  Several instances on different streams run concurrently (speculative
+// candidate window of the incremental mode).
+template <class T>
+class PersistSolver {
+public:
+    using Dev = typename T::Dev;
+    double term_eps = 0.0;
+    int max_helpers = 39;                       // workgroups besides the leader (75 KB of LDS each)
+
+    ~PersistSolver() { release(); }
+
+    hipError_t launch(hipStream_t st, const double* chain, int estride, const double* cand, int cstride, const double* src,
+                      int src_ld, int lo, int hi, const std::vector<int>& members, const int* from, const int* to,
+                      int iterations)
+    {
+        const int L = hi - lo, nl = (int)members.size(), n = T::kD * nl;
+        IPC_CL_CHK(ensure(L, nl));
+        const int ld = L + 2;
+        Dev& D = dev_;
+        D.chain = chain; D.estride = estride; D.lo = lo; D.L = L; D.nl = nl; D.ld = ld;
+        D.cand = cand; D.cstride = cstride;
+        T::carve(D, d_edge_, d_loop_, ld, nl);
+        D.S = d_S_; D.ldS = n + 1;
+        D.partial = nullptr; D.scal = nullptr;
+        tab_.build(lo, hi, members, from, to);
+        std::memcpy(h_tab_, tab_.host.data(), sizeof(int) * tab_.size());
+        IPC_CL_CHK(hipMemcpyAsync(d_int_, h_tab_, sizeof(int) * tab_.size(), hipMemcpyHostToDevice, st));
+        D.lfrom = tab_.lfrom(d_int_); D.lto = tab_.lto(d_int_); D.lcand = tab_.lcand(d_int_);
+        D.adj_ptr = tab_.adj_ptr(d_int_); D.adj_item = tab_.adj_item(d_int_);
+        D.ev_ptr = tab_.ev_ptr(d_int_); D.ev_item = tab_.ev_item(d_int_);
+        IPC_CL_CHK(hipMemsetAsync(d_ctl_, 0, sizeof(PersistCtl), st));
+        // workgroups: the leader + one helper per four 64 x 64 tiles of the first trailing update
+        const int nt = (n + 63) / 64;
+        const int tiles0 = n > 64 ? nt * (nt + 1) / 2 : 0;
+        int G = 1 + std::min(max_helpers, (tiles0 + kPSG - 1) / kPSG);
+        if (tiles0 == 0) G = 1;
+        PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_};
+        static bool attr_set = false;
+        if (!attr_set) {
+            IPC_CL_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_persist_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kLdsTotal)));
+            attr_set = true;
+        }
+        Dev D1 = D;
+        T::exchange(D1);
+        hipLaunchKernelGGL(cluster_persist_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P);
+        IPC_CL_CHK(hipGetLastError());
+        IPC_CL_CHK(hipMemcpyAsync(h_out_, d_out_, sizeof(PersistOut), hipMemcpyDeviceToHost, st));
+        st_ = st;
+        last_G_ = G;
+        return hipSuccess;
+    }
+
+    hipError_t wait(ClusterOut& out)
+    {
+        IPC_CL_CHK(hipStreamSynchronize(st_));
+        out = ClusterOut{};
+        out.max_chi2 = h_out_->max_chi2; out.chi2_total = h_out_->chi2_total; out.chi2_initial = h_out_->chi2_initial;
+        out.iterations = h_out_->iterations; out.tries = h_out_->tries; out.flags = h_out_->flags; out.evals = h_out_->evals;
+        x_sel_ = h_out_->x_sel;
+        return h_out_->error ? hipErrorLaunchFailure : hipSuccess;
+    }
+
+    const Dev& dev() const { return dev_; }
+    bool result_in_second() const { return x_sel_ != 0; }
+    int ld() const { return dev_.ld; }
+    int workgroups() const { return last_G_; }
+
+private:
+    Dev dev_{};
+    hipStream_t st_ = nullptr;
+    int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
+    double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
+    int* d_int_ = nullptr;
+    int* h_tab_ = nullptr;
+    PersistCtl* d_ctl_ = nullptr;
+    PersistOut *d_out_ = nullptr, *h_out_ = nullptr;
+    LoopTables tab_;
+
+    void release()
+    {
+        hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_); hipFree(d_ctl_); hipFree(d_out_);
+        if (h_out_) hipHostFree(h_out_);
+        if (h_tab_) hipHostFree(h_tab_);
+        d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; d_ctl_ = nullptr; d_out_ = h_out_ = nullptr; h_tab_ = nullptr;
+        capL_ = capNl_ = 0;
+    }
+    hipError_t ensure(int L, int nl)
+    {
+        if (!h_out_) {
+            IPC_CL_CHK(hipHostMalloc(&h_out_, sizeof(PersistOut)));
+            IPC_CL_CHK(hipMalloc(&d_out_, sizeof(PersistOut)));
+            IPC_CL_CHK(hipMalloc(&d_ctl_, sizeof(PersistCtl)));
+        }
+        if (L > capL_ || nl > capNl_) {
+            const int nL = std::max(L, capL_), nN = std::max(nl, capNl_);
+            hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_);
+            if (h_tab_) hipHostFree(h_tab_);
+            d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; h_tab_ = nullptr;
+            capL_ = capNl_ = 0;
+            const size_t ld = (size_t)nL + 2, n = (size_t)T::kD * nN;
+            IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (T::kEdgeDoubles * ld + ld + nN)));
+            IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (T::kLoopDoubles * (size_t)nN + 8)));
+            IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * 2 * (n + 1) * n));
+            IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (n + kCB)));
+            IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
+            IPC_CL_CHK(hipHostMalloc(&h_tab_, sizeof(int) * LoopTables::capacity(nL, nN)));
+            capL_ = nL; capNl_ = nN;
+        }
+        return hipSuccess;
+    }
+};
+
+}  // namespace ipc

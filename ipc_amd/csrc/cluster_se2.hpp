@@ -51,10 +51,8 @@ __device__ __forceinline__ Sym3 gk_sym(const double* base, int stride, int field
 }
 
 // errors + chi2 of the poses Y (trial or committed); edges 1..L then loops
-__global__ void gk_eval(ClusterDev D, PoseArr Y, double* eo, double* leo)
+__device__ __forceinline__ void gk_eval_at(const ClusterDev& D, const PoseArr& Y, double* eo, double* leo, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(Y, i - 1), b = gk_pose(Y, i);
@@ -74,13 +72,18 @@ __global__ void gk_eval(ClusterDev D, PoseArr Y, double* eo, double* leo)
         leo[l] = e0; leo[D.nl + l] = e1; leo[2 * D.nl + l] = e2;
         v[0] = gk_sym(D.cand, D.cstride, F_OM, c).quad(e0, e1, e2);
     }
+}
+__global__ void gk_eval(ClusterDev D, PoseArr Y, double* eo, double* leo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk_eval_at(D, Y, eo, leo, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
 // per-edge chi2 of the committed state (output for the per-edge threshold test)
-__global__ void gk_chi_edges(ClusterDev D)
+__device__ __forceinline__ void gk_chi_edges_at(const ClusterDev& D, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         D.chi_edges[i - 1] = gk_sym(D.chain, D.estride, F_OM, k).quad(D.e[i], D.e[D.ld + i], D.e[2 * D.ld + i]);
@@ -89,11 +92,15 @@ __global__ void gk_chi_edges(ClusterDev D)
         D.chi_edges[D.L + l] = gk_sym(D.cand, D.cstride, F_OM, D.lcand[l]).quad(D.le[l], D.le[D.nl + l], D.le[2 * D.nl + l]);
     }
 }
-
-// forces g = (P q_t, q_th), hand-backs m = (g_t, g_th + (J dt).g_t), Gamma_l
-__global__ void gk_force(ClusterDev D)
+__global__ void gk_chi_edges(ClusterDev D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk_chi_edges_at(D, i);
+}
+
+// forces g = (P q_t, q_th), hand-backs m = (g_t, g_th + (J dt).g_t), Gamma_l
+__device__ __forceinline__ void gk_force_at(const ClusterDev& D, int i)
+{
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
@@ -126,12 +133,15 @@ __global__ void gk_force(ClusterDev D)
         G[6 * D.nl + l] = 0.0;     G[7 * D.nl + l] = 0.0;    G[8 * D.nl + l] = sg;
     }
 }
+__global__ void gk_force(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk_force_at(D, i);
+}
 
 // b_j = m_{j+1} - g_j + loop terms; partial b^T b
-__global__ void gk_b(ClusterDev D)
+__device__ __forceinline__ void gk_b_at(const ClusterDev& D, int j, double (&v)[1])
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (j >= 1 && j <= D.L) {
         double b0 = -D.g[j], b1 = -D.g[D.ld + j], b2 = -D.g[2 * D.ld + j];
         if (j < D.L) { b0 += D.m[j + 1]; b1 += D.m[D.ld + j + 1]; b2 += D.m[2 * D.ld + j + 1]; }
@@ -143,14 +153,18 @@ __global__ void gk_b(ClusterDev D)
         D.b[j] = b0; D.b[D.ld + j] = b1; D.b[2 * D.ld + j] = b2;
         v[0] = b0 * b0 + b1 * b1 + b2 * b2;
     }
+}
+__global__ void gk_b(ClusterDev D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk_b_at(D, j, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
 // partial b^T H b = sum_e |J_e b|^2_Om ; also Psi_j / w_j (before the prefix sums)
-__global__ void gk_bHb_psi(ClusterDev D)
+__device__ __forceinline__ void gk_bHb_psi_at(const ClusterDev& D, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
@@ -194,14 +208,18 @@ __global__ void gk_bHb_psi(ClusterDev D)
 #pragma unroll
         for (int k = 0; k < 9; ++k) D.ps[k * D.ld] = 0.0;
     }
+}
+__global__ void gk_bHb_psi(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk_bHb_psi_at(D, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
 // capacitance system: S (lower triangle, column major) and rhs
-__global__ void gk_assemble(ClusterDev D)
+__device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int l2)     // row block l1, column block l2
 {
-    const int l2 = blockIdx.x * blockDim.x + threadIdx.x;     // column block
-    const int l1 = blockIdx.y;                                 // row block
     if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
     const int NS = 3 * D.nl;
     const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
@@ -231,7 +249,7 @@ __global__ void gk_assemble(ClusterDev D)
         for (int c = 0; c < 3; ++c) {
             double t = GM[r][0] * G2[c][0] + GM[r][1] * G2[c][1] + GM[r][2] * G2[c][2];
             if (l1 == l2) t += Sg[r][c];
-            D.S[(size_t)(3 * l2 + c) * D.ldS + (3 * l1 + r)] = t;
+            st_shared(&D.S[(size_t)(3 * l2 + c) * D.ldS + (3 * l1 + r)], t);
         }
     if (l1 == l2) {
         const double W0 = D.ps[6 * D.ld + hi1] - D.ps[6 * D.ld + lo1];
@@ -239,14 +257,17 @@ __global__ void gk_assemble(ClusterDev D)
         const double W2 = D.ps[8 * D.ld + hi1] - D.ps[8 * D.ld + lo1];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            D.S[(size_t)(3 * l1 + r) * D.ldS + NS] = D.le[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2);
+            st_shared(&D.S[(size_t)(3 * l1 + r) * D.ldS + NS], D.le[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2));
     }
+}
+__global__ void gk_assemble(ClusterDev D)
+{
+    gk_assemble_at(D, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // nu_l = Gamma_l^T mu_l
-__global__ void gk_nu(ClusterDev D)
+__device__ __forceinline__ void gk_nu_at(const ClusterDev& D, int l)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= D.nl) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -256,11 +277,15 @@ __global__ void gk_nu(ClusterDev D)
         D.nu[c * D.nl + l] = t;
     }
 }
+__global__ void gk_nu(ClusterDev D)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    gk_nu_at(D, l);
+}
 
 // nd[j] = sum of the events at index j (+nu at the start of a loop range, -nu one past its end)
-__global__ void gk_events(ClusterDev D)
+__device__ __forceinline__ void gk_events_at(const ClusterDev& D, int j)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > D.L + 1) return;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (j >= 1) {
@@ -272,11 +297,15 @@ __global__ void gk_events(ClusterDev D)
     }
     D.nd[j] = a0; D.nd[D.ld + j] = a1; D.nd[2 * D.ld + j] = a2;
 }
+__global__ void gk_events(ClusterDev D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    gk_events_at(D, j);
+}
 
 // u_j = -Cov Phi^T n_j - e_j ; rho = (P u_t, u_th): rho_th -> sc[0], rho_t -> sc[1], sc[2]
-__global__ void gk_rho(ClusterDev D)
+__device__ __forceinline__ void gk_rho_at(const ClusterDev& D, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 1 || i > D.L) return;
     const int k = D.lo + i - 1;
     const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
@@ -292,34 +321,45 @@ __global__ void gk_rho(ClusterDev D)
     D.sc[D.ld + i] = c * ux - sn * uy;
     D.sc[2 * D.ld + i] = sn * ux + c * uy;
 }
-// term = rho_t + J dt h_theta(j-1)  (sc[0] already holds the inclusive theta prefix)
-__global__ void gk_term(ClusterDev D)
+__global__ void gk_rho(ClusterDev D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk_rho_at(D, i);
+}
+// term = rho_t + J dt h_theta(j-1)  (sc[0] already holds the inclusive theta prefix)
+__device__ __forceinline__ void gk_term_at(const ClusterDev& D, int i)
+{
     if (i < 1 || i > D.L) return;
     const double thPrev = i > 1 ? D.sc[i - 1] : 0.0;
     const double dx = D.X.x[i] - D.X.x[i - 1], dy = D.X.y[i] - D.X.y[i - 1];
     D.sc[D.ld + i] += -dy * thPrev;
     D.sc[2 * D.ld + i] += dx * thPrev;
 }
-// h = (sc1, sc2, sc0); partial |h|^2, b.h
-__global__ void gk_h(ClusterDev D)
+__global__ void gk_term(ClusterDev D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[2] = {0.0, 0.0};
+    gk_term_at(D, i);
+}
+// h = (sc1, sc2, sc0); partial |h|^2, b.h
+__device__ __forceinline__ void gk_h_at(const ClusterDev& D, int i, double (&v)[2])
+{
     if (i >= 1 && i <= D.L) {
         const double h0 = D.sc[D.ld + i], h1 = D.sc[2 * D.ld + i], h2 = D.sc[i];
         D.h[i] = h0; D.h[D.ld + i] = h1; D.h[2 * D.ld + i] = h2;
         v[0] = h0 * h0 + h1 * h1 + h2 * h2;
         v[1] = D.b[i] * h0 + D.b[D.ld + i] * h1 + D.b[2 * D.ld + i] * h2;
     }
-    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
 }
-// c = hsd.(hgn - hsd), |hgn - hsd|^2 for the dog-leg blend
-__global__ void gk_blend(ClusterDev D, double alpha)
+__global__ void gk_h(ClusterDev D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v[2] = {0.0, 0.0};
+    gk_h_at(D, i, v);
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+// c = hsd.(hgn - hsd), |hgn - hsd|^2 for the dog-leg blend
+__device__ __forceinline__ void gk_blend_at(const ClusterDev& D, double alpha, int i, double (&v)[2])
+{
     if (i >= 1 && i <= D.L) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -328,13 +368,17 @@ __global__ void gk_blend(ClusterDev D, double alpha)
             v[1] += ak * ak;
         }
     }
+}
+__global__ void gk_blend(ClusterDev D, double alpha)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    gk_blend_at(D, alpha, i, v);
     gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
 }
 // trial poses Xn = X (+) (p b + q h); partial "changed" count
-__global__ void gk_update(ClusterDev D, double p, double q)
+__device__ __forceinline__ void gk_update_at(const ClusterDev& D, double p, double q, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i == 0) { D.Xn.x[0] = D.X.x[0]; D.Xn.y[0] = D.X.y[0]; D.Xn.th[0] = D.X.th[0]; D.Xn.c[0] = D.X.c[0]; D.Xn.s[0] = D.X.s[0]; }
     if (i >= 1 && i <= D.L) {
         const double x = D.X.x[i] + fma(p, D.b[i], q * D.h[i]);
@@ -345,6 +389,12 @@ __global__ void gk_update(ClusterDev D, double p, double q)
         D.Xn.x[i] = x; D.Xn.y[i] = y; D.Xn.th[i] = th; D.Xn.c[i] = c; D.Xn.s[i] = s;
         v[0] = (x != D.X.x[i] || y != D.X.y[i] || th != D.X.th[i]) ? 1.0 : 0.0;
     }
+}
+__global__ void gk_update(ClusterDev D, double p, double q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk_update_at(D, p, q, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 

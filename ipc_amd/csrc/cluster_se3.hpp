@@ -85,10 +85,8 @@ __device__ __forceinline__ void gk3_phi(const Pose3& X, const Edge3& E, const do
 }
 
 // errors + chi2 of the poses Y; edges 1..L then loops
-__global__ void gk3_eval(ClusterDev3 D, const double* Y, double* eo, double* leo)
+__device__ __forceinline__ void gk3_eval_at(const ClusterDev3& D, const double* Y, double* eo, double* leo, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         double Rz[9], tz[3], om[21];
@@ -108,12 +106,17 @@ __global__ void gk3_eval(ClusterDev3 D, const double* Y, double* eo, double* leo
         gk3_sym(D.cand, D.cstride, G_OM, c, om);
         v[0] = sym6_quad(om, E.e);
     }
+}
+__global__ void gk3_eval(ClusterDev3 D, const double* Y, double* eo, double* leo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk3_eval_at(D, Y, eo, leo, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
-__global__ void gk3_chi_edges(ClusterDev3 D)
+__device__ __forceinline__ void gk3_chi_edges_at(const ClusterDev3& D, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double om[21], e[6];
     if (i >= 1 && i <= D.L) {
         gk3_sym(D.chain, D.estride, G_OM, D.lo + i - 1, om);
@@ -126,11 +129,15 @@ __global__ void gk3_chi_edges(ClusterDev3 D)
         D.chi_edges[D.L + l] = sym6_quad(om, e);
     }
 }
-
-// g = D^T Om e, m = Ad^T g (odometry and loops); Gamma_l
-__global__ void gk3_force(ClusterDev3 D)
+__global__ void gk3_chi_edges(ClusterDev3 D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk3_chi_edges_at(D, i);
+}
+
+// g = D^T Om e, m = Ad^T g (odometry and loops); Gamma_l
+__device__ __forceinline__ void gk3_force_at(const ClusterDev3& D, int i)
+{
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         double Rz[9], tz[3], om[21], e[6], qo[6], g[6], m[6];
@@ -179,12 +186,15 @@ __global__ void gk3_force(ClusterDev3 D)
             }
     }
 }
+__global__ void gk3_force(ClusterDev3 D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk3_force_at(D, i);
+}
 
 // b_j = m_{j+1} - g_j + loop terms; partial b^T b
-__global__ void gk3_b(ClusterDev3 D)
+__device__ __forceinline__ void gk3_b_at(const ClusterDev3& D, int j, double (&v)[1])
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (j >= 1 && j <= D.L) {
         double b[6];
 #pragma unroll
@@ -204,14 +214,18 @@ __global__ void gk3_b(ClusterDev3 D)
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[0] += b[k] * b[k];
     }
+}
+__global__ void gk3_b(ClusterDev3 D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk3_b_at(D, j, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
 // partial b^T H b; Psi_j / w_j before the prefix sums
-__global__ void gk3_bHb_psi(ClusterDev3 D)
+__device__ __forceinline__ void gk3_bHb_psi_at(const ClusterDev3& D, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         double Rz[9], tz[3], om[21], sg[21], va[6] = {0, 0, 0, 0, 0, 0}, vb[6], w[6], e[6];
@@ -277,14 +291,18 @@ __global__ void gk3_bHb_psi(ClusterDev3 D)
 #pragma unroll
         for (int k = 0; k < 27; ++k) D.ps[(size_t)k * D.ld] = 0.0;
     }
+}
+__global__ void gk3_bHb_psi(ClusterDev3 D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk3_bHb_psi_at(D, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
 // capacitance system: S (lower triangle of 6x6 blocks, column major) and rhs
-__global__ void gk3_assemble(ClusterDev3 D)
+__device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, int l2)     // row block l1, column block l2
 {
-    const int l2 = blockIdx.x * blockDim.x + threadIdx.x;     // column block
-    const int l1 = blockIdx.y;                                 // row block
     if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
     const int NS = 6 * D.nl;
     const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
@@ -313,22 +331,25 @@ __global__ void gk3_assemble(ClusterDev3 D)
 #pragma unroll
             for (int q = 0; q < 6; ++q) acc += T[q] * D.gam[(size_t)(6 * c + q) * D.nl + l2];
             if (l1 == l2) acc += sgl[sym6_idx(r, c)];
-            D.S[(size_t)(6 * l2 + c) * D.ldS + (6 * l1 + r)] = acc;
+            st_shared(&D.S[(size_t)(6 * l2 + c) * D.ldS + (6 * l1 + r)], acc);
         }
         if (l1 == l2) {
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 acc += g1[q] * (D.ps[(size_t)(21 + q) * D.ld + hi1] - D.ps[(size_t)(21 + q) * D.ld + lo1]);
-            D.S[(size_t)(6 * l1 + r) * D.ldS + NS] = D.le[(size_t)r * D.nl + l1] - acc;
+            st_shared(&D.S[(size_t)(6 * l1 + r) * D.ldS + NS], D.le[(size_t)r * D.nl + l1] - acc);
         }
     }
 }
+__global__ void gk3_assemble(ClusterDev3 D)
+{
+    gk3_assemble_at(D, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // nu_l = Gamma_l^T mu_l
-__global__ void gk3_nu(ClusterDev3 D)
+__device__ __forceinline__ void gk3_nu_at(const ClusterDev3& D, int l)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= D.nl) return;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -338,10 +359,14 @@ __global__ void gk3_nu(ClusterDev3 D)
         D.nu[(size_t)c * D.nl + l] = t;
     }
 }
-
-__global__ void gk3_events(ClusterDev3 D)
+__global__ void gk3_nu(ClusterDev3 D)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    gk3_nu_at(D, l);
+}
+
+__device__ __forceinline__ void gk3_events_at(const ClusterDev3& D, int j)
+{
     if (j > D.L + 1) return;
     double a[6] = {0, 0, 0, 0, 0, 0};
     if (j >= 1) {
@@ -354,11 +379,15 @@ __global__ void gk3_events(ClusterDev3 D)
     }
     gk3_st6(D.nd, D.ld, j, a);
 }
+__global__ void gk3_events(ClusterDev3 D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    gk3_events_at(D, j);
+}
 
 // u_j = -Cov Phi^T n_j - e_j, rho = D^-1 u;  R_j rho_q -> sc[0..2], R_j rho_t -> sc[3..5]
-__global__ void gk3_rho(ClusterDev3 D)
+__device__ __forceinline__ void gk3_rho_at(const ClusterDev3& D, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 1 || i > D.L) return;
     const int k = D.lo + i - 1;
     double Rz[9], tz[3], sg[21], nn[6], e[6];
@@ -387,10 +416,14 @@ __global__ void gk3_rho(ClusterDev3 D)
 #pragma unroll
     for (int q = 0; q < 3; ++q) { D.sc[(size_t)q * D.ld + i] = rq[q]; D.sc[(size_t)(3 + q) * D.ld + i] = rt[q]; }
 }
-// term = R rho_t + 2 omega_{j-1} x (t_j - t_{j-1})   (sc[0..2] already holds the inclusive omega prefix)
-__global__ void gk3_term(ClusterDev3 D)
+__global__ void gk3_rho(ClusterDev3 D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    gk3_rho_at(D, i);
+}
+// term = R rho_t + 2 omega_{j-1} x (t_j - t_{j-1})   (sc[0..2] already holds the inclusive omega prefix)
+__device__ __forceinline__ void gk3_term_at(const ClusterDev3& D, int i)
+{
     if (i < 1 || i > D.L) return;
     double op[3] = {0, 0, 0}, d3[3], c[3];
     if (i > 1) {
@@ -403,11 +436,14 @@ __global__ void gk3_term(ClusterDev3 D)
 #pragma unroll
     for (int q = 0; q < 3; ++q) D.sc[(size_t)(3 + q) * D.ld + i] += 2 * c[q];
 }
-// h = (R^T tau, R^T omega); partial |h|^2, b.h
-__global__ void gk3_h(ClusterDev3 D)
+__global__ void gk3_term(ClusterDev3 D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[2] = {0.0, 0.0};
+    gk3_term_at(D, i);
+}
+// h = (R^T tau, R^T omega); partial |h|^2, b.h
+__device__ __forceinline__ void gk3_h_at(const ClusterDev3& D, int i, double (&v)[2])
+{
     if (i >= 1 && i <= D.L) {
         double R[9], om3[3], ta3[3], h[6], b[6];
 #pragma unroll
@@ -421,12 +457,16 @@ __global__ void gk3_h(ClusterDev3 D)
 #pragma unroll
         for (int q = 0; q < 6; ++q) { v[0] += h[q] * h[q]; v[1] += b[q] * h[q]; }
     }
-    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
 }
-__global__ void gk3_blend(ClusterDev3 D, double alpha)
+__global__ void gk3_h(ClusterDev3 D)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v[2] = {0.0, 0.0};
+    gk3_h_at(D, i, v);
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+__device__ __forceinline__ void gk3_blend_at(const ClusterDev3& D, double alpha, int i, double (&v)[2])
+{
     if (i >= 1 && i <= D.L) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -435,13 +475,17 @@ __global__ void gk3_blend(ClusterDev3 D, double alpha)
             v[1] += ak * ak;
         }
     }
+}
+__global__ void gk3_blend(ClusterDev3 D, double alpha)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    gk3_blend_at(D, alpha, i, v);
     gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
 }
 // trial poses Xn = X * fromVectorMQT(p b + q h) (VertexSE3::oplusImpl); partial "changed" count
-__global__ void gk3_update(ClusterDev3 D, double p, double q)
+__device__ __forceinline__ void gk3_update_at(const ClusterDev3& D, double p, double q, int i, double (&v)[1])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[1] = {0.0};
     if (i == 0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) D.Xn[(size_t)k * D.ld] = D.X[(size_t)k * D.ld];
@@ -468,6 +512,12 @@ __global__ void gk3_update(ClusterDev3 D, double p, double q)
         }
         v[0] = chg ? 1.0 : 0.0;
     }
+}
+__global__ void gk3_update(ClusterDev3 D, double p, double q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    gk3_update_at(D, p, q, i, v);
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 

@@ -22,6 +22,7 @@
 #include "cell_kernels.hpp"
 #include "cluster_se2.hpp"
 #include "cluster_se3.hpp"
+#include "cluster_persist.hpp"
 
 using namespace ipc;
 
@@ -545,6 +546,10 @@ struct ipc_engine {
     double* d_cur = nullptr;                           // [5][V] current estimates
     ClusterSolver2* cluster = nullptr;
     ClusterSolver3* cluster3 = nullptr;                // SE3: d_open is d_pose0 itself, d_cur is [12][V]
+    // device-resident dog-leg (cluster_persist.hpp): the default; IPC_CLUSTER_MODE=host keeps the host-driven kernels
+    bool persist = true;
+    PersistSolver<PersistSe2>* persist2 = nullptr;
+    PersistSolver<PersistSe3>* persist3 = nullptr;
 };
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
@@ -571,6 +576,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (const char* te = getenv("IPC_TERMINATE_EPS")) {
         if (*te) h->term_eps = atof(te);
         if (!(h->term_eps >= 0) || h->term_eps > 1e-6) { delete h; return fail(IPC_ERR_ARG, "IPC_TERMINATE_EPS must be in [0, 1e-6]"); }
+    }
+    if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
+        if (!strcmp(cm, "host")) h->persist = false;
+        else if (*cm && strcmp(cm, "persist")) { delete h; return fail(IPC_ERR_ARG, "IPC_CLUSTER_MODE must be 'persist' or 'host'"); }
     }
     const int E = n_vertices - 1;
     const int ms = dim == 2 ? 3 : 7, is = dim == 2 ? 6 : 21, nf = dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
@@ -659,6 +668,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
     delete h->cluster;
     delete h->cluster3;
+    delete h->persist2;
+    delete h->persist3;
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -792,6 +803,40 @@ static Se3View make_view3(const ipc_engine* h)
 static int ensure_incremental(ipc_engine* h, const char* who);
 static PoseArr pose_arr(double* base, int V);
 
+// One cluster solve (chain lo..hi of the records `chain` + the loops `members`, from the poses `src`: SE2 [5][V],
+// SE3 [12][V]) on the engine's stream, by the device-resident dog-leg or (IPC_CLUSTER_MODE=host) the host-driven one.
+// Blocks until the result record is back; the optimised poses stay in the solver (cluster_result2 / cluster_result3).
+static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src, int lo, int hi, const std::vector<int>& members,
+                                int iters, ClusterOut& o)
+{
+    if (h->persist) {
+        if (h->dim == 3) {
+            IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                           h->h_from.data(), h->h_to.data(), iters));
+            return h->persist3->wait(o);
+        }
+        IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                       h->h_from.data(), h->h_to.data(), iters));
+        return h->persist2->wait(o);
+    }
+    if (h->dim == 3)
+        return h->cluster3->solve(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                  h->h_from.data(), h->h_to.data(), iters, o, nullptr);
+    return h->cluster->solve(h->own_stream, chain, h->estride, h->d_cand, h->cstride, pose_arr(src, h->V), lo, hi, members,
+                             h->h_from.data(), h->h_to.data(), iters, o, nullptr);
+}
+static PoseArr cluster_result2(const ipc_engine* h)
+{
+    if (!h->persist) return h->cluster->result();
+    return h->persist2->result_in_second() ? h->persist2->dev().Xn : h->persist2->dev().X;
+}
+static const double* cluster_result3(const ipc_engine* h, int& ld)
+{
+    if (!h->persist) { ld = h->cluster3->ld(); return h->cluster3->result(); }
+    ld = h->persist3->ld();
+    return h->persist3->result_in_second() ? h->persist3->dev().Xn : h->persist3->dev().X;
+}
+
 // Cells beyond the capacity of every cell kernel (SE3 > 4096 poses, SE2 > 16384 with the default
 // policies): the same check (reference src/consensus_utils.cpp:7-22 on chain lo..hi + the one or two
 // loop edges, open-loop start, fast / slow iteration base) through the cluster solver, whose state
@@ -817,13 +862,7 @@ static int solve_long_cells(ipc_engine* h, hipStream_t st, int nb, const unsigne
             int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
             if ((hi - lo) + nl > 100) iters *= 5;                              // consensus_utils.cpp:12-13
             ClusterOut o;
-            if (h->dim == 3)
-                HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_open, h->V,
-                                          lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
-            else
-                HIPCHK(h->cluster->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride,
-                                         pose_arr(h->d_open, h->V), lo, hi, members, h->h_from.data(), h->h_to.data(),
-                                         iters, o, nullptr));
+            HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o));
             chi[c] = o.max_chi2; tot[c] = o.chi2_total;
             meta[c] = make_int4(o.iterations, o.tries, o.flags, o.evals);
         }
@@ -1180,6 +1219,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
             HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
         }
         if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; }
+        if (!h->persist3) { h->persist3 = new PersistSolver<PersistSe3>(); h->persist3->term_eps = h->term_eps; }
         return IPC_OK;
     }
     if (!h->d_open) {
@@ -1191,6 +1231,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
     if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; }
+    if (!h->persist2) { h->persist2 = new PersistSolver<PersistSe2>(); h->persist2->term_eps = h->term_eps; }
     return IPC_OK;
 }
 
@@ -1242,13 +1283,13 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
     if ((hi - lo) + (int)members.size() > 100) iters *= 5;                   // consensus_utils.cpp:12-13
     ClusterOut o;
     if (h->dim == 3) {
-        HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V,
-                                  lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
+        HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, lo, hi, members, iters, o));
         const bool agree3 = !(o.max_chi2 > th);
         if (agree3) {
-            HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, h->cluster3->result(),
-                                    sizeof(double) * h->cluster3->ld(), sizeof(double) * (hi - lo + 1), 12,
-                                    hipMemcpyDeviceToDevice, h->own_stream));
+            int rld = 0;
+            const double* res = cluster_result3(h, rld);
+            HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, res, sizeof(double) * rld,
+                                    sizeof(double) * (hi - lo + 1), 12, hipMemcpyDeviceToDevice, h->own_stream));
             if (hi + 1 < h->V)
                 hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, h->own_stream, h->V, hi, h->d_chain,
                                    h->estride, h->d_cur);
@@ -1260,11 +1301,10 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
         fill_info(info, lo, hi, nclu, o);
         return IPC_OK;
     }
-    HIPCHK(h->cluster->solve(h->own_stream, h->d_chain, h->estride, h->d_cand, h->cstride, pose_arr(h->d_cur, h->V),
-                             lo, hi, members, h->h_from.data(), h->h_to.data(), iters, o, nullptr));
+    HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, lo, hi, members, iters, o));
     const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
     if (agree) {                                                              // :69-71
-        const PoseArr& X = h->cluster->result();
+        const PoseArr X = cluster_result2(h);
         const double* xs[5] = {X.x, X.y, X.th, X.c, X.s};
         for (int f = 0; f < 5; ++f)
             HIPCHK(hipMemcpyAsync(h->d_cur + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1),
@@ -1392,15 +1432,52 @@ extern "C" int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int 
     }
     ClusterOut o;
     if (h->dim == 3) {
-        HIPCHK(h->cluster3->solve(h->own_stream, h->d_chain1, h->estride, h->d_cand, h->cstride, h->d_open, h->V,
-                                  0, h->V - 1, members, h->h_from.data(), h->h_to.data(), iterations, o, nullptr));
+        HIPCHK(cluster_solve(h, h->d_chain1, h->d_open, 0, h->V - 1, members, iterations, o));
         fill_info(info, 0, h->V - 1, (int)members.size(), o);
-        if (poses_out) return download_poses3(h, h->cluster3->result(), h->cluster3->ld(), h->V, poses_out);
+        int rld = 0;
+        const double* res = cluster_result3(h, rld);
+        if (poses_out) return download_poses3(h, res, rld, h->V, poses_out);
         return IPC_OK;
     }
-    HIPCHK(h->cluster->solve(h->own_stream, h->d_chain1, h->estride, h->d_cand, h->cstride, pose_arr(h->d_open, h->V),
-                             0, h->V - 1, members, h->h_from.data(), h->h_to.data(), iterations, o, nullptr));
+    HIPCHK(cluster_solve(h, h->d_chain1, h->d_open, 0, h->V - 1, members, iterations, o));
     fill_info(info, 0, h->V - 1, (int)members.size(), o);
-    if (poses_out) return download_poses(h, h->cluster->result(), h->V, poses_out);
+    if (poses_out) return download_poses(h, cluster_result2(h), h->V, poses_out);
     return IPC_OK;
 }
+
+// Diagnostic: solve the dense SPD system of a cluster's capacitance matrix as the incremental mode does.
+// system: (n+1) x n column major, lower triangle of S in rows 0..n-1, right-hand side in row n.
+// mode 0: dense_chol.hpp (one launch per block column), mode 1: the persistent orchestration with `workgroups`.
+extern "C" int ipc_debug_dense_solve(int n, const double* system, int mode, int workgroups, double* x_out, int* info_out)
+{
+    if (n < 1 || !system || !x_out || !info_out) return fail(IPC_ERR_ARG, "ipc_debug_dense_solve: bad argument");
+    const size_t m = (size_t)(n + 1) * n;
+    double *dA = nullptr, *dx = nullptr, *ddinv = nullptr;
+    int* dinfo = nullptr;
+    PersistCtl* dctl = nullptr;
+    HIPCHK(hipMalloc(&dA, sizeof(double) * 2 * m));
+    HIPCHK(hipMalloc(&dx, sizeof(double) * (n + 64)));
+    HIPCHK(hipMalloc(&ddinv, sizeof(double) * (n + 64)));
+    HIPCHK(hipMalloc(&dinfo, sizeof(int)));
+    HIPCHK(hipMalloc(&dctl, sizeof(PersistCtl)));
+    HIPCHK(hipMemcpy(dA, system, sizeof(double) * m, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dA + m, 0, sizeof(double) * m));
+    HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
+    HIPCHK(hipMemset(dctl, 0, sizeof(PersistCtl)));
+    if (mode == 0) {
+        HIPCHK(chol_solve_device(dA, dA + m, n, dx, dinfo, nullptr));
+    } else {
+        if (workgroups < 1 || workgroups > 200) return fail(IPC_ERR_ARG, "ipc_debug_dense_solve: workgroups %d", workgroups);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchol_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(double) * kLdsTotal)));
+        hipLaunchKernelGGL(pchol_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, dA, dA + m, ddinv, n,
+                           dx, dctl, dinfo);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);
+    return IPC_OK;
+}
+

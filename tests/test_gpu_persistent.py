@@ -1,0 +1,201 @@
+"""The device-resident dog-leg (ipc_amd/csrc/cluster_persist.hpp: one persistent launch per cluster solve, the
+engine's default) against
+
+  * the host-driven solver it replaces (IPC_CLUSTER_MODE=host): same arithmetic in the same order, so every
+    number of every check must agree BIT FOR BIT -- a lost update or a stale read across workgroups shows here;
+  * committed expectations of the CPU oracle's faithful run (tests/golden/*_incremental_expected.npz, written by
+    tests/golden/make_incremental_golden.py) on the bench workloads C1 (clusters up to 253 accepted loops: capacitance
+    systems of 759 unknowns, the multi-tile Cholesky), C2 (all 1256 candidates) and an SE3 graph with clusters of
+    59 loops (354 unknowns): decision, cluster span and size, max edge chi2 within 1e-5 -- IPC::agreementCheck,
+    reference src/consensus.cpp:43-75,124-171.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _engine(g, cfg, mode):
+    from ipc_amd.consensus import IPC
+    old = os.environ.get("IPC_CLUSTER_MODE")
+    os.environ["IPC_CLUSTER_MODE"] = mode
+    try:
+        return IPC(g, cfg, device=0)
+    finally:
+        if old is None:
+            del os.environ["IPC_CLUSTER_MODE"]
+        else:
+            os.environ["IPC_CLUSTER_MODE"] = old
+
+
+def _run(eng, order):
+    eng.reset()
+    rec = []
+    for k in order:
+        ok, info = eng.agreementCheck(int(k), with_info=True)
+        rec.append((ok, info.lo, info.hi, info.n_cluster_loops, info.iterations, info.tries, info.flags,
+                    info.max_chi2, info.chi2_total, info.chi2_initial))
+    return rec
+
+
+def _assert_bitwise(a, b):
+    assert len(a) == len(b)
+    for q, (ra, rb) in enumerate(zip(a, b)):
+        assert ra[:7] == rb[:7], (q, ra, rb)
+        for x, y in zip(ra[7:], rb[7:]):
+            assert np.float64(x).tobytes() == np.float64(y).tobytes() or (x != x and y != y), (q, ra, rb)
+
+
+def _dense_solve(lib, system, n, mode, wgs):
+    import ctypes as C
+    from ipc_amd import capi
+    x = np.zeros(n)
+    info = C.c_int(0)
+    capi.check(lib.ipc_debug_dense_solve(n, system.ctypes.data_as(C.c_void_p), mode, wgs, x.ctypes.data_as(C.c_void_p),
+                                         C.byref(info)))
+    return x, info.value
+
+
+@pytest.mark.parametrize("n", [5, 24, 32, 33, 64, 65, 97, 130, 200, 401, 759])
+def test_dense_solve_persistent_orchestration_equals_launch_per_column(n):
+    """The blocked Cholesky inside the persistent kernel (grid barriers, sc1 traffic, diagonal block one step ahead on
+    workgroup 0) returns the bits of dense_chol.hpp's launch-per-block-column factorisation, for any number of
+    workgroups; both solve the system."""
+    from ipc_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, n))
+    S = B @ B.T + n * np.eye(n)
+    d = rng.normal(size=n)
+    system = np.zeros((n, n + 1))                 # column major (n+1) x n: system[c, r] = element (r, c)
+    system[:, :n] = np.tril(S).T                  # lower triangle: rows r >= c of column c
+    system[:, n] = d
+    system = np.ascontiguousarray(system)
+    x0, info0 = _dense_solve(lib, system, n, 0, 0)
+    assert info0 == 0
+    assert np.allclose(x0, np.linalg.solve(S, d), rtol=1e-9, atol=1e-12)
+    for wgs in (1, 2, 3, 8, 33):
+        x1, info1 = _dense_solve(lib, system, n, 1, wgs)
+        assert info1 == 0, (n, wgs)
+        assert np.array_equal(x0.view(np.uint64), x1.view(np.uint64)), (n, wgs, np.abs(x0 - x1).max())
+
+
+def test_dense_solve_reports_a_non_positive_pivot():
+    from ipc_amd import capi
+    lib = capi.load()
+    n = 70
+    S = np.eye(n)
+    S[40, 40] = -1.0
+    system = np.zeros((n, n + 1))
+    system[:, :n] = np.tril(S).T
+    system[:, n] = 1.0
+    _, i0 = _dense_solve(lib, np.ascontiguousarray(system), n, 0, 0)
+    _, i1 = _dense_solve(lib, np.ascontiguousarray(system), n, 1, 3)
+    assert i0 == i1 == 33                          # 1 + first column of the block column holding the pivot
+
+
+@pytest.mark.parametrize("seed", [5, 11])
+def test_persistent_equals_host_driven_se2(seed):
+    """Clusters of tens of loops: capacitance systems up to ~80 unknowns = one or two block columns, helpers on."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    g = synth._se2_graph(400, 24, seed=70 + seed, laps=3.0, name="inc")
+    g = synth.inject_outliers(g, 16, seed=seed)
+    cfg = Config()
+    ep, eh = _engine(g, cfg, "persist"), _engine(g, cfg, "host")
+    order = ep.candidate_order()
+    _assert_bitwise(_run(ep, order), _run(eh, order))
+    assert np.array_equal(ep.current_poses().view(np.uint64), eh.current_poses().view(np.uint64))
+
+
+def test_persistent_equals_host_driven_se2_large_clusters():
+    """T700-like graph, first 150 candidates: clusters beyond 40 loops (> 128 unknowns: several tiles, the
+    one-step-ahead diagonal block of workgroup 0, the skipped corner of tile (0, 0))."""
+    import bench
+    g, cfg, _ = bench.build_workload("T700")
+    ep, eh = _engine(g, cfg, "persist"), _engine(g, cfg, "host")
+    order = ep.candidate_order()[:150]
+    rp, rh = _run(ep, order), _run(eh, order)
+    assert max(r[3] for r in rp) >= 20
+    _assert_bitwise(rp, rh)
+    assert np.array_equal(ep.current_poses().view(np.uint64), eh.current_poses().view(np.uint64))
+
+
+def test_persistent_equals_host_driven_se3():
+    import bench
+    g, cfg, _ = bench.build_workload("C4s")
+    ep, eh = _engine(g, cfg, "persist"), _engine(g, cfg, "host")
+    order = ep.candidate_order()
+    rp, rh = _run(ep, order), _run(eh, order)
+    assert max(r[3] for r in rp) >= 40
+    _assert_bitwise(rp, rh)
+    assert np.array_equal(ep.current_poses().view(np.uint64), eh.current_poses().view(np.uint64))
+
+
+def test_final_map_persistent_equals_host_driven():
+    import bench
+    g, cfg, _ = bench.build_workload("tiny")
+    ep, eh = _engine(g, cfg, "persist"), _engine(g, cfg, "host")
+    acc = np.zeros(g.N, dtype=np.uint8)
+    acc[:cfg.canonic_inliers] = 1
+    pp, ip = ep.final_optimize(acc)
+    ph, ih = eh.final_optimize(acc)
+    assert (ip.iterations, ip.tries, ip.flags) == (ih.iterations, ih.tries, ih.flags)
+    assert np.float64(ip.chi2_total).tobytes() == np.float64(ih.chi2_total).tobytes()
+    assert np.array_equal(pp.view(np.uint64), ph.view(np.uint64))
+
+
+def _replay(workload, tag, pose_atol):
+    import bench
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = bench.build_workload(workload)
+    exp = np.load(os.path.join(GOLD, "%s_incremental_expected.npz" % tag))
+    assert int(np.asarray(g.loop_ids, dtype=np.int64).sum()) == int(exp["loop_ids_checksum"]), "workload changed"
+    assert abs(float(np.asarray(g.loop_meas).sum()) - float(exp["meas_checksum"])) < 1e-9, "workload changed"
+    eng = IPC(g, cfg, device=0)
+    order = eng.candidate_order()
+    assert np.array_equal(order, exp["order"])
+    eng.reset()
+    worst = 0.0
+    flips = []
+    for q, k in enumerate(order):
+        ok, info = eng.agreementCheck(int(k), with_info=True)
+        assert (info.lo, info.hi, info.n_cluster_loops) == (int(exp["lo"][q]), int(exp["hi"][q]), int(exp["cluster"][q])), (q, k)
+        if ok != bool(exp["decision"][q]):
+            flips.append((q, int(k), info.max_chi2, float(exp["max_chi2"][q])))
+            break                                   # the states diverge from here on
+        ref = float(exp["max_chi2"][q])
+        err = abs(info.max_chi2 - ref) / max(abs(ref), 1e-12)
+        worst = max(worst, err)
+        assert err <= REL, (q, int(k), info.max_chi2, ref, info.iterations, int(exp["iterations"][q]))
+    assert not flips, flips
+    assert np.array_equal(eng.getMaxConsensusSet(), exp["consensus"])
+    got, ref = eng.current_poses(), exp["poses"]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= pose_atol or g.dim == 2
+    if g.dim == 2:
+        assert np.abs(got[:, :2] - ref[:, :2]).max() <= pose_atol
+        assert np.abs(np.angle(np.exp(1j * (got[:, 2] - ref[:, 2])))).max() <= pose_atol
+    return worst, int(exp["cluster"].max())
+
+
+def test_c1_faithful_run_against_the_oracle_fixture():
+    """bench.py workload C1, all 356 candidates: clusters up to 253 accepted loops = 759 unknowns."""
+    worst, big = _replay("C1", "c1", 1e-6)
+    assert big >= 250
+
+
+def test_se3_faithful_run_against_the_oracle_fixture():
+    worst, big = _replay("C4s", "se3", 1e-6)
+    assert big >= 40
+
+
+def test_c2_faithful_run_against_the_oracle_fixture():
+    """bench.py workload C2 (the north-star configuration), all 1256 candidates."""
+    worst, big = _replay("C2", "c2", 1e-6)
+    assert big >= 100
