@@ -26,24 +26,22 @@ constexpr int kGB = 256;                     // threads per block of the grid ke
 __device__ __forceinline__ double ld_shared(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_shared(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Block sum of K per-thread values (blocks of kGB = 256 threads): a DPP scan inside each wave, then the four wave
+// totals in wave order.  The persistent kernel (cluster_persist.hpp::lead_reduce) adds in exactly this order.
 template <int K>
 __device__ __forceinline__ void gk_block_reduce_store(double (&v)[K], double* partial_row)
 {
-    __shared__ double shm[K][kGB];
+    __shared__ double shm[K][kGB / 64];
     const int t = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < K; ++k) shm[k][t] = v[k];
-    __syncthreads();
-    for (int s = kGB / 2; s > 0; s >>= 1) {
-        if (t < s) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) shm[k][t] += shm[k][t + s];
-        }
-        __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const double ws = wave_sum(v[k]);
+        if ((t & 63) == 0) shm[k][t >> 6] = ws;
     }
+    __syncthreads();
     if (t == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) partial_row[k] = shm[k][0];
+        for (int k = 0; k < K; ++k) partial_row[k] = ((shm[k][0] + shm[k][1]) + shm[k][2]) + shm[k][3];
     }
 }
 

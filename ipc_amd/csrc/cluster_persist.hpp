@@ -48,6 +48,7 @@ struct PersistArgs {
     int iterations; double term_eps;
     PersistCtl* ctl; PersistOut* out;
     double* dinv;                            // [n] reciprocal pivots of the factor
+    unsigned long long* prof;                // optional [16] phase clocks of the leader (IPC_PERSIST_PROF=1), 100 MHz ticks
 };
 
 // ---- LDS carve-up (doubles) -------------------------------------------------------------------------------
@@ -56,11 +57,27 @@ constexpr int kLdsDinv = kCB * (kCB + 1);                  // [32]
 constexpr int kLdsR = kLdsDinv + kCB;                      // phase-private region
 constexpr int kLdsPanel = kCB * (64 + 1);                  // one [32][65] panel
 constexpr int kLdsTotal = kLdsR + kPSG * 2 * kLdsPanel;    // 17 728 doubles = 141 824 bytes
-// leader's use of the region: reduction staging [kPSG][2][256], results [8], scan partials [9][16]
-constexpr int kLdsRed = kLdsR, kLdsRes = kLdsRed + kPSG * 2 * 256, kLdsWsum = kLdsRes + 8, kLdsMisc = kLdsWsum + 9 * 16;
+// leader's use of the region: reduction staging [kLeadMaxBlk runs][4 waves][2], results [8], scan partials [9][16]
+constexpr int kLeadMaxBlk = 700;            // runs of 256 indices the reduction staging holds (L + nl < 179 200)
+constexpr int kLdsRed = kLdsR, kLdsRes = kLdsRed + kLeadMaxBlk * 4 * 2, kLdsWsum = kLdsRes + 8, kLdsMisc = kLdsWsum + 9 * 16;
 static_assert(kLdsMisc + 64 <= kLdsTotal, "LDS carve-up");
 
-struct GridBar { unsigned* ctr; unsigned target; int G; int* error; };
+struct GridBar { unsigned* ctr; unsigned target; int G; int* error; unsigned long long* prof; };
+
+// phase clocks (thread 0 of workgroup 0 only; prof == nullptr: off)
+enum { kProfTotal = 0, kProfPre, kProfHandoff, kProfAssemble, kProfFactor, kProfFactorWork, kProfFactorWait, kProfBacksolve,
+       kProfPost, kProfTrial, kProfRest, kProfIterations, kProfSteps,
+       kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfN };
+__device__ __forceinline__ unsigned long long prof_now() { return wall_clock64(); }
+__device__ __forceinline__ void prof_add(unsigned long long* prof, int slot, unsigned long long t0)
+{
+    if (prof && threadIdx.x == 0 && blockIdx.x == 0) prof[slot] += prof_now() - t0;
+}
+// the first helper's clocks (slots kProfHelp*)
+__device__ __forceinline__ void prof_add1(unsigned long long* prof, int slot, unsigned long long t0)
+{
+    if (prof && threadIdx.x == 0 && blockIdx.x == 1) prof[slot] += prof_now() - t0;
+}
 
 // Every workgroup arrives once; leaves when all G have.  Monotonic counter, relaxed sc1 poll with s_sleep.  The
 // caller's cross-workgroup stores are sc1 (write-through) and are drained by the s_waitcnt before the arrival.
@@ -91,47 +108,37 @@ __device__ __forceinline__ void lead_for(int n, F f)
 }
 
 // Sum of K per-index values over indices 0 .. nblk*256-1, added exactly as gk_block_reduce_store + gk_sum add them:
-// a binary tree inside each run of 256 indices, then the runs in ascending order.
+// a DPP scan inside each run of 64 indices, the four wave totals of a run of 256 in order, the runs in ascending order.
+// One __syncthreads() per phase (plus one before the staging area is reused).
 template <int K, class F>
 __device__ __forceinline__ void lead_reduce(int nblk, double* lds, double (&tot)[K], F f)
 {
-    double* red = lds + kLdsRed;
-    double* res = lds + kLdsRes;
+    double* wpart = lds + kLdsRed;                            // [nblk][4][K]
     const int tid = threadIdx.x, q = tid >> 8, t = tid & 255;
-    double acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0;
     for (int vb0 = 0; vb0 < nblk; vb0 += kPSG) {
         const int vb = vb0 + q;
         double v[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = 0.0;
         if (vb < nblk) f(vb * 256 + t, v);
+        double ws[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) red[(q * K + k) * 256 + t] = v[k];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (t < s) {
+        for (int k = 0; k < K; ++k) ws[k] = wave_sum(v[k]);
+        if (vb < nblk) {                                      // (wave-uniform; every lane stores the same value)
 #pragma unroll
-                for (int k = 0; k < K; ++k) red[(q * K + k) * 256 + t] += red[(q * K + k) * 256 + t + s];
-            }
-            __syncthreads();
+            for (int k = 0; k < K; ++k) wpart[(vb * 4 + (t >> 6)) * K + k] = ws[k];
         }
-        if (tid == 0) {
-            for (int qq = 0; qq < kPSG && vb0 + qq < nblk; ++qq) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc[k] += red[(qq * K + k) * 256];
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) res[k] = acc[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) tot[k] = res[k];
+    for (int k = 0; k < K; ++k) {
+        double acc = 0.0;
+        for (int vb = 0; vb < nblk; ++vb) {
+            const double* w = wpart + (size_t)vb * 4 * K + k;
+            acc += ((w[0] + w[K]) + w[2 * K]) + w[3 * K];
+        }
+        tot[k] = acc;
+    }
     __syncthreads();
 }
 
@@ -151,26 +158,36 @@ __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* 
 #pragma unroll
         for (int hp = 0; hp < NP; ++hp) {
             const int i = base + hp * kPT + tid;
+            const int ic = i <= L ? i : 0;                    // (index 0 is a valid, unused slot of every row: no predicated loads)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                v[hp][k] = i <= L ? arr[(size_t)k * ld + i] : 0.0;
-                v[hp][k] = wave_inclusive_scan(v[hp][k]);
-                if (lane == 63) wsum[k * 16 + hp * NW + wave] = v[hp][k];
+                const double a = arr[(size_t)k * ld + ic];
+                v[hp][k] = wave_inclusive_scan(i <= L ? a : 0.0);
+                wsum[k * 16 + hp * NW + wave] = read_lane(v[hp][k], 63);      // (uniform value, every lane stores it)
             }
         }
         __syncthreads();
+        double res[NP][K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             double tt = carry[k];
             for (int w = 0; w < 16; ++w) tt += wsum[k * 16 + w];
 #pragma unroll
             for (int hp = 0; hp < NP; ++hp) {
-                const int i = base + hp * kPT + tid, vw = hp * NW + wave;
+                const int vw = hp * NW + wave;
                 double off = carry[k];
                 for (int w = 0; w < vw; ++w) off += wsum[k * 16 + w];
-                if (i <= L) arr[(size_t)k * ld + i] = v[hp][k] + off;
+                res[hp][k] = v[hp][k] + off;
             }
             carry[k] = tt;
+        }
+#pragma unroll
+        for (int hp = 0; hp < NP; ++hp) {
+            const int i = base + hp * kPT + tid;
+            if (i <= L) {                                     // (one branch around the K stores)
+#pragma unroll
+                for (int k = 0; k < K; ++k) arr[(size_t)k * ld + i] = res[hp][k];
+            }
         }
         __syncthreads();
     }
@@ -191,19 +208,27 @@ __device__ __noinline__ bool potrf32_wave(double (*Dn)[kCB + 1], double* Dninv)
     double row[kCB];
 #pragma unroll
     for (int c = 0; c < kCB; ++c) row[c] = Dn[r][c];
+    // Lane r holds row r; column c reaches the other rows through v_readlane.  The 32 pivots are one dependent
+    // chain (pivot -> rsq -> two Newton steps -> column -> next pivot); the rank-one update of the columns beyond
+    // c + 1 does not feed it, so it is written BEHIND the start of the next pivot's chain and fills its latency.
+    double piv = read_lane(row[0], 0);
+    if (!(piv > 0)) ok = false;
+    double inv = rsqrt_newton(piv);
 #pragma unroll
     for (int c = 0; c < kCB; ++c) {
-        const double piv = read_lane(row[c], c);
-        if (!(piv > 0)) ok = false;
-        const double inv = rsqrt_newton(piv);
-        const double lrc = r == c ? piv * inv : (r > c ? row[c] * inv : 0.0);
+        // (lane c: row[c] IS the pivot, so one product serves the diagonal and the column; rows above pick up
+        // garbage that nothing reads: lrc is forced to 0 for r < c, only the lower triangle is written back)
+        const double lrc = r >= c ? row[c] * inv : 0.0;
         row[c] = lrc;
-        if (lane == c) Dninv[c] = inv;
-#pragma unroll
-        for (int cc = c + 1; cc < kCB; ++cc) {
-            const double lcc = read_lane(lrc, cc);
-            row[cc] = fma(-lrc, lcc, row[cc]);
+        Dninv[c] = inv;                                       // (every lane stores the same value: no exec juggling)
+        if (c + 1 < kCB) {
+            row[c + 1] = fma(-lrc, read_lane(lrc, c + 1), row[c + 1]);
+            piv = read_lane(row[c + 1], c + 1);
+            if (!(piv > 0)) ok = false;
+            inv = rsqrt_newton(piv);
         }
+#pragma unroll
+        for (int cc = c + 2; cc < kCB; ++cc) row[cc] = fma(-lrc, read_lane(lrc, cc), row[cc]);
     }
     if (lane < kCB) {
 #pragma unroll
@@ -222,38 +247,91 @@ __device__ __forceinline__ void publish_block(double (*Dn)[kCB + 1], const doubl
     if (threadIdx.x < nbb) st_shared(&dinv[kb0 + threadIdx.x], Dninv[threadIdx.x]);
 }
 
+// Panel solve x L^T = a against the factored 32 x 32 block of the column, one row per lane, x in registers.
+// DT is the block as the tiles use it: DT[p][c] = L[c][p] for c > p (a straight copy of the factor's column p, which
+// is stored contiguously), DT[p][p] = 1 / L[p][p]; columns beyond a short block are identity.  Column by column: once
+// x[p] is final it is taken out of every later column -- the subtractions reach each x[c] in the order p = 0, 1, ...
+// (a dot-product form's order, without its dependent chain); the block's columns come from LDS at uniform addresses
+// (broadcast reads).
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+template <class Store>
+__device__ __forceinline__ void trsm32(double (&x)[kCB], const double* DT_generic, Store store)
+{
+    // The block's LDS address goes through a register the compiler cannot see into: with a link-time constant base
+    // it materialises every one of the 500 element addresses in its own SGPR (spilled through v_writelane) instead
+    // of using the instruction's immediate offset.
+    unsigned dt_off = (unsigned)(size_t)(lds_cdouble*)DT_generic;
+    asm volatile("" : "+v"(dt_off));
+    lds_cdouble* DT = (lds_cdouble*)(size_t)dt_off;
+    double cur[kCB];
+#pragma unroll
+    for (int c = 0; c < kCB; ++c) cur[c] = DT[c];
+#pragma unroll
+    for (int p = 0; p < kCB; ++p) {
+        x[p] = x[p] * cur[p];
+#pragma unroll
+        for (int c = p + 1; c < kCB; ++c) x[c] -= x[p] * cur[c];
+        store(p, x[p]);
+        // The next column of the block is requested as one batch right behind the products (left alone, the scheduler
+        // sinks every read next to its use: read, wait, two FMAs, read, wait ...); it lands in the registers of the
+        // column just applied, so the solve holds x and one column: a second buffer spilled.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = p + 1; c < kCB; ++c) cur[c] = DT[(p + 1) * kCB + c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // One 64 x 64 tile (bx >= by) of the trailing update of block column k0, by one 256-thread sub-group; the two
 // __syncthreads() are workgroup-wide, so every sub-group of the workgroup calls this the same number of times
-// (has = false: no tile this round).  D / Dinv: the factored diagonal block of the column, in LDS.
+// (has = false: no tile this round).  DT: the factored diagonal block of the column as trsm32 reads it, in LDS.
 // skip_next_diag: leave rows / columns k1 .. k1+32 (the next diagonal block, inside tile (0, 0)) untouched.
-__device__ __noinline__ void chol_tile(double* A, double* Lf, int n, int ld, int k0, int nb, bool has, int bx, int by,
-                                          double (*D)[kCB + 1], const double* Dinv, double* panel, bool skip_next_diag)
+__device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, int k0, int nb, bool has, int bx, int by,
+                                          const double* DT, double* panel, bool skip_next_diag, unsigned long long* prof)
 {
     const int t = threadIdx.x & 255, wv = t >> 6, lane = t & 63;
     const int k1 = k0 + nb;
     const int i0 = k1 + bx * 64, j0 = k1 + by * 64;
     double (*Ai)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel);
     double (*Aj)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel + kLdsPanel);
+    const int tx = t & 15, ty = t >> 4;
+    const unsigned long long ts0 = prof_now();
     if (has && wv < 2) {
         double x[kCB];
         const int prow = wv == 0 ? i0 + lane : j0 + lane;
         const bool pvalid = wv == 0 ? prow <= n : prow < n;           // row n (rhs) only ever is a tile ROW
+        // (address clamped instead of a predicated load: 32 loads in flight, not 32 blocks with one round trip each)
 #pragma unroll
-        for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? ld_shared(&A[(size_t)(k0 + c) * ld + prow]) : 0.0;
+        for (int c = 0; c < kCB; ++c) x[c] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+#pragma unroll
+        for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
         double (*P)[64 + 1] = wv == 0 ? Ai : Aj;
+        trsm32(x, DT, [&](int p, double v) { P[p][lane] = p < nb ? v : 0.0; });
+        // (one branch around all the stores: a conditional store per column splits the unrolled solve into 32 blocks
+        // and the register allocator gives up -- 1.5 KB of scratch per lane)
+        if (wv == 0 && by == 0 && pvalid) {
 #pragma unroll
-        for (int c = 0; c < kCB; ++c) {
-            double v = x[c];
-#pragma unroll
-            for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
-            x[c] = v * Dinv[c];
-            P[c][lane] = c < nb ? x[c] : 0.0;
-            if (wv == 0 && by == 0 && c < nb && pvalid) st_shared(&Lf[(size_t)(k0 + c) * ld + prow], x[c]);
+            for (int p = 0; p < kCB; ++p)
+                if (p < nb) st_shared(&Lf[(size_t)(k0 + p) * ld + prow], x[p]);
         }
     }
     __syncthreads();
+    prof_add1(prof, kProfHelpSolve, ts0);
+    const unsigned long long tu0 = prof_now();
     if (has && j0 < n) {
-        const int tx = t & 15, ty = t >> 4;
+        // the tile's old values: all sixteen loads in flight behind the product below (sc1: straight from memory;
+        // one load - subtract - store per element would be sixteen round trips)
+        double old[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + ty + 16 * b;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + tx + 16 * a;
+                const bool in = j < n && i <= n && i >= j;
+                old[a][b] = ld_shared(&A[in ? (size_t)j * ld + i : (size_t)0]);         // (always a valid address: no branch per element)
+            }
+        }
         double acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -278,14 +356,12 @@ __device__ __noinline__ void chol_tile(double* A, double* Lf, int n, int ld, int
                 const int i = i0 + tx + 16 * a;
                 // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
                 if (skip_next_diag && i < min(k1 + kCB, n)) continue;       // (row n is the right-hand side, never part of it)
-                if (i <= n && i >= j) {
-                    double* p = &A[(size_t)j * ld + i];
-                    st_shared(p, ld_shared(p) - acc[a][b]);
-                }
+                if (i <= n && i >= j) st_shared(&A[(size_t)j * ld + i], old[a][b] - acc[a][b]);
             }
         }
     }
     __syncthreads();
+    prof_add1(prof, kProfHelpUpdate, tu0);
 }
 
 // Factor the (n+1) x n system A (row n = right-hand side) into Lf / dinv; all G workgroups call it together.
@@ -293,13 +369,19 @@ __device__ __noinline__ void chol_tile(double* A, double* Lf, int n, int ld, int
 __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, int n, GridBar& gb, double* lds, bool& alive)
 {
     const int ld = n + 1, g = blockIdx.x, G = gb.G, tid = threadIdx.x, sg = tid >> 8;
-    double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
-    double* Dinv = lds + kLdsDinv;
+    double* DT = lds + kLdsD;                                  // [32][32] factored block of the current column (trsm32 layout)
     // workgroup 0's private blocks: panel rows of the next diagonal block, the block itself, its reciprocal pivots
-    double (*Lrow)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR);
-    double (*Dn)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR + kCB * (kCB + 1));
-    double* Dninv = lds + kLdsR + 2 * kCB * (kCB + 1);
+    double (*Lrow)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(lds + kLdsR);          // (a slot per lane of the wave: stores need no predicate)
+    double (*Dn)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR + kLdsPanel);
+    double* Dninv = lds + kLdsR + kLdsPanel + kCB * (kCB + 1);
     int info = 0;
+    // the factored block Dn / Dninv -> DT (workgroup 0 keeps the block it has just factored: no trip through memory)
+    auto dn_to_dt = [&](int nbb) {
+        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+            const int c = idx >> 5, r = idx & 31;              // DT[c][r] = L[r][c]
+            DT[idx] = (r < nbb && c < nbb) ? (r > c ? Dn[r][c] : (r == c ? Dninv[c] : 0.0)) : (r == c ? 1.0 : 0.0);
+        }
+    };
     if (g == 0) {                                             // diagonal block 0 straight from the system
         const int nb0 = min(kCB, n);
         for (int idx = tid; idx < kCB * kCB; idx += kPT) {
@@ -309,20 +391,27 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
         __syncthreads();
         bool ok = true;
         if (tid < 64) ok = potrf32_wave(Dn, Dninv);
-        if (tid == 0 && !ok) lds[kLdsMisc] = 1.0; else if (tid == 0) lds[kLdsMisc] = 0.0;
+        if (tid == 0) lds[kLdsMisc] = ok ? 0.0 : 1.0;
         __syncthreads();
         if (lds[kLdsMisc] != 0.0) info = 1;
         publish_block(Dn, Dninv, Lf, dinv, ld, 0, nb0);
+        dn_to_dt(nb0);
     }
     alive = grid_barrier(gb);
     for (int k0 = 0; k0 < n && alive; k0 += kCB) {
+        const unsigned long long tw0 = prof_now();
         const int nb = min(kCB, n - k0), k1 = k0 + nb;
-        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
-            const int r = idx % kCB, c = idx / kCB;
-            D[r][c] = (r < nb && c < nb && r >= c) ? ld_shared(&Lf[(size_t)(k0 + c) * ld + k0 + r]) : (r == c ? 1.0 : 0.0);
+        if (g > 0) {                                          // helpers fetch the block workgroup 0 published
+            const unsigned long long th0 = prof_now();
+            for (int idx = tid; idx < kCB * kCB; idx += kPT) {
+                const int c = idx >> 5, r = idx & 31;
+                const bool in = r < nb && c < nb;
+                const double v = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[(size_t)(k0 + c) * ld + k0 + r]) : &dinv[k0]);
+                DT[idx] = in ? (r >= c ? v : 0.0) : (r == c ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            prof_add1(gb.prof, kProfHelpDT, th0);
         }
-        if (tid < kCB) Dinv[tid] = tid < nb ? ld_shared(&dinv[k0 + tid]) : 1.0;
-        __syncthreads();
         const bool tiles_here = G == 1 || g > 0;
         if (tiles_here) {
             const int nti = (n + 1 - k1 + 63) / 64, ntj = max((n - k1 + 63) / 64, 1);
@@ -335,8 +424,8 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                 const bool has = tt < total;
                 int by = 0, rem = tt;
                 if (has) { while (rem >= nti - by) { rem -= nti - by; ++by; } }
-                chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, D, Dinv, lds + kLdsR + sg * 2 * kLdsPanel,
-                          G > 1 && has && by == 0 && rem == 0);
+                chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
+                          G > 1 && has && by == 0 && rem == 0, gb.prof);
             }
         }
         if (g == 0 && k1 < n) {
@@ -349,45 +438,68 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                     Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[(size_t)(k1 + c) * ld + k1 + r]) : (r == c ? 1.0 : 0.0);
                 }
             } else {
-                // one step ahead of the helpers: rows k1 .. k1+nb2 of block column k0 against D, then the update of
-                // the next diagonal block with them -- the same operations, in the same order, as chol_tile applies
+                // One step ahead of the helpers: rows k1 .. k1+nb2 of block column k0 against the block, then the
+                // update of the next diagonal block with them -- the same operations, in the same order, as chol_tile
+                // applies.  The old values of that block are requested together with the panel rows (one round trip).
+                unsigned long long tl0 = prof_now();
+                constexpr int kTri = kCB * (kCB + 1) / 2, kTriPass = (kTri + kPT - 1) / kPT;    // lower-triangle elements
+                double oldv[kTriPass];
+                int er[kTriPass], es[kTriPass];
+#pragma unroll
+                for (int q = 0; q < kTriPass; ++q) {
+                    const int idx = tid + q * kPT;
+                    int r = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+                    if (r * (r + 1) / 2 > idx) --r;
+                    if ((r + 1) * (r + 2) / 2 <= idx) ++r;
+                    er[q] = r; es[q] = idx - r * (r + 1) / 2;
+                    const bool in = idx < kTri && r < nb2;                                      // (sc <= r < nb2)
+                    oldv[q] = ld_shared(&A[in ? (size_t)(k1 + es[q]) * ld + k1 + r : (size_t)0]);
+                }
                 if (tid < 64) {
                     const int lane = tid, prow = k1 + lane;
                     const bool pvalid = lane < nb2;
                     double x[kCB];
 #pragma unroll
-                    for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? ld_shared(&A[(size_t)(k0 + c) * ld + prow]) : 0.0;
+                    for (int c = 0; c < kCB; ++c) x[c] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
 #pragma unroll
-                    for (int c = 0; c < kCB; ++c) {
-                        double v = x[c];
-#pragma unroll
-                        for (int p = 0; p < c; ++p) v -= x[p] * D[c][p];
-                        x[c] = v * Dinv[c];
-                        if (lane < kCB) Lrow[c][lane] = c < nb ? x[c] : 0.0;
-                    }
+                    for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
+                    prof_add(gb.prof, kProfLookLoad, tl0); tl0 = prof_now();
+                    trsm32(x, DT, [&](int p, double v) { Lrow[p][lane] = p < nb ? v : 0.0; });
                 }
+                // identity padding / zeros above the diagonal, then the lower triangle on top
+                for (int idx = tid; idx < kCB * kCB; idx += kPT) Dn[idx >> 5][idx & 31] = (idx >> 5) == (idx & 31) ? 1.0 : 0.0;
                 __syncthreads();
-                for (int idx = tid; idx < kCB * kCB; idx += kPT) {
-                    const int r = idx >> 5, s = idx & 31;
-                    double val = r == s ? 1.0 : 0.0;
-                    if (r < nb2 && s < nb2 && s <= r) {
+                prof_add(gb.prof, kProfLookSolve, tl0); tl0 = prof_now();
+#pragma unroll
+                for (int q = 0; q < kTriPass; ++q) {
+                    const int idx = tid + q * kPT, r = er[q], sc = es[q];
+                    if (idx < kTri && r < nb2) {
                         double acc = 0.0;
 #pragma unroll 8
-                        for (int p = 0; p < kCB; ++p) acc = fma(Lrow[p][r], Lrow[p][s], acc);
-                        val = ld_shared(&A[(size_t)(k1 + s) * ld + k1 + r]) - acc;
+                        for (int p = 0; p < kCB; ++p) acc = fma(Lrow[p][r], Lrow[p][sc], acc);
+                        Dn[r][sc] = oldv[q] - acc;
                     }
-                    Dn[r][s] = val;
                 }
+                prof_add(gb.prof, kProfLookFill, tl0);
             }
             __syncthreads();
+            unsigned long long tp0 = prof_now();
             bool ok = true;
             if (tid < 64) ok = potrf32_wave(Dn, Dninv);
             if (tid == 0) lds[kLdsMisc] = ok ? 0.0 : 1.0;
             __syncthreads();
+            prof_add(gb.prof, kProfLookPotrf, tp0); tp0 = prof_now();
             if (lds[kLdsMisc] != 0.0 && info == 0) info = k1 + 1;
             publish_block(Dn, Dninv, Lf, dinv, ld, k1, nb2);
+            dn_to_dt(nb2);                                    // (the tiles / the panel solve of this step are done with DT)
+            prof_add(gb.prof, kProfLookPub, tp0);
         }
+        prof_add(gb.prof, kProfFactorWork, tw0);
+        const unsigned long long tb0 = prof_now();
         alive = grid_barrier(gb);
+        prof_add(gb.prof, kProfFactorWait, tb0);
+        prof_add1(gb.prof, kProfHelpWait, tb0);
+        if (gb.prof && threadIdx.x == 0 && blockIdx.x == 0) gb.prof[kProfSteps] += 1;
     }
     return info;
 }
@@ -436,7 +548,7 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
 __global__ __launch_bounds__(kPT, 1) void pchol_test_kernel(double* A, double* Lf, double* dinv, int n, double* x, PersistCtl* ctl, int* info)
 {
     extern __shared__ double lds[];
-    GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error};
+    GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error, nullptr};
     bool alive = true;
     const int r = pchol_factor(A, Lf, dinv, n, gb, lds, alive);
     if (blockIdx.x == 0) {
@@ -551,7 +663,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     const typename T::Dev* Dp = &D0;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
-    GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error};
+    GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error, P.prof};
     const int L = Dp->L, nl = Dp->nl, ld = Dp->ld;
     const int n = T::kD * nl;
     double* A = Dp->S;
@@ -580,6 +692,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     }
 
     // ---- leader ----
+    const unsigned long long tk0 = prof_now();
     const int nidx = L + nl + 1, nblk = (nidx + 255) / 256;
     int n_commit = 0;
     lead_for(L + 1, [&](int i) { T::load_initial((*Dp), P.src, P.src_ld, i); });
@@ -591,10 +704,12 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     };
     // H h_gn = b through the capacitance system; returns the solver's info word
     auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
+        unsigned long long t0 = prof_now();
         lead_for(nidx, [&](int i) { T::force((*Dp), i); });
         { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::b((*Dp), i, v); }); bb = tot[0]; }
         { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::bHb_psi((*Dp), i, v); }); bHb = tot[0]; }
         lead_scan(Dp->ps, T::kNPS, L, ld, lds);
+        prof_add(P.prof, kProfPre, t0); t0 = prof_now();
         // hand the assembly's inputs to the helpers, factor together
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -605,11 +720,15 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         alive = grid_barrier(gb);                                                            // B1
+        prof_add(P.prof, kProfHandoff, t0); t0 = prof_now();
         assemble_share((*Dp));
         if (alive) alive = grid_barrier(gb);                                                 // B2
+        prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
         if (alive) info = pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
+        prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
         pchol_backsolve(Lf, n, Dp->rhs, lds);
+        prof_add(P.prof, kProfBacksolve, t0); t0 = prof_now();
         lead_for(nl, [&](int l) { T::nu((*Dp), l); });
         lead_for(L + 2, [&](int j) { T::events((*Dp), j); });
         lead_scan(Dp->nd, T::kNND, L, ld, lds);
@@ -618,6 +737,8 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         lead_for(nidx, [&](int i) { T::term((*Dp), i); });
         lead_scan(Dp->sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds);
         { double tot[2]; lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::h((*Dp), i, v); }); hh = tot[0]; bh = tot[1]; }
+        prof_add(P.prof, kProfPost, t0);
+        if (P.prof && tid == 0) P.prof[kProfIterations] += 1;
         return info;
     };
 
@@ -646,6 +767,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         const double deltaAtEntry = delta;
         bool goodStep = false;
         int numTries = 0;
+        const unsigned long long tt0 = prof_now();
         do {
             ++numTries;
             int stepType;
@@ -694,6 +816,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
                 }
             }
         } while (!goodStep && numTries < maxTrials);
+        prof_add(P.prof, kProfTrial, tt0);
         lastGN = goodStep && numTries == 1 && hgnNorm < deltaAtEntry;
         o.iterations = it + 1;
         o.tries += numTries;
@@ -727,6 +850,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             o.x_sel = n_commit & 1;
             o.error = alive ? 0 : 1;
             *P.out = o;
+            prof_add(P.prof, kProfTotal, tk0);
         }
     }
 }
@@ -740,6 +864,7 @@ class PersistSolver {
 public:
     using Dev = typename T::Dev;
     double term_eps = 0.0;
+    unsigned long long* d_prof = nullptr;       // optional device buffer [kProfN] the leader accumulates its phase clocks into
     int max_helpers = 39;                       // workgroups besides the leader (75 KB of LDS each)
 
     ~PersistSolver() { release(); }
@@ -769,7 +894,7 @@ public:
         const int tiles0 = n > 64 ? nt * (nt + 1) / 2 : 0;
         int G = 1 + std::min(max_helpers, (tiles0 + kPSG - 1) / kPSG);
         if (tiles0 == 0) G = 1;
-        PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_};
+        PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_, d_prof};
         static bool attr_set = false;
         if (!attr_set) {
             IPC_CL_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_persist_kernel<T>),
@@ -798,6 +923,8 @@ public:
 
     const Dev& dev() const { return dev_; }
     bool result_in_second() const { return x_sel_ != 0; }
+    // problems the leader's LDS staging cannot hold go to the host-driven solver
+    static bool fits(int L, int nl) { return (L + nl + 1 + 255) / 256 <= kLeadMaxBlk; }
     int ld() const { return dev_.ld; }
     int workgroups() const { return last_G_; }
 

@@ -548,8 +548,11 @@ struct ipc_engine {
     ClusterSolver3* cluster3 = nullptr;                // SE3: d_open is d_pose0 itself, d_cur is [12][V]
     // device-resident dog-leg (cluster_persist.hpp): the default; IPC_CLUSTER_MODE=host keeps the host-driven kernels
     bool persist = true;
+    bool last_persist = false;                         // which solver holds the poses of the last cluster solve
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
+    unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
+    int max_helpers = -1;                              // IPC_PERSIST_HELPERS
 };
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
@@ -577,6 +580,13 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         if (*te) h->term_eps = atof(te);
         if (!(h->term_eps >= 0) || h->term_eps > 1e-6) { delete h; return fail(IPC_ERR_ARG, "IPC_TERMINATE_EPS must be in [0, 1e-6]"); }
     }
+    if (const char* pp = getenv("IPC_PERSIST_PROF")) {
+        if (*pp && strcmp(pp, "0")) {
+            if (hipMalloc(&h->d_prof, sizeof(unsigned long long) * kProfN) != hipSuccess) h->d_prof = nullptr;
+            else hipMemset(h->d_prof, 0, sizeof(unsigned long long) * kProfN);
+        }
+    }
+    if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
         else if (*cm && strcmp(cm, "persist")) { delete h; return fail(IPC_ERR_ARG, "IPC_CLUSTER_MODE must be 'persist' or 'host'"); }
@@ -668,6 +678,19 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
     delete h->cluster;
     delete h->cluster3;
+    if (h->d_prof) {
+        unsigned long long p[kProfN] = {};
+        hipDeviceSynchronize();
+        hipMemcpy(p, h->d_prof, sizeof(p), hipMemcpyDeviceToHost);
+        static const char* names[kProfN] = {"total", "pre", "handoff", "assemble", "factor", "factor_work", "factor_wait", "backsolve",
+                                            "post", "trial", "rest", "iterations", "steps", "help_dt", "help_solve", "help_update", "help_wait",
+                                            "look_load", "look_solve", "look_fill", "look_potrf", "look_publish"};
+        fprintf(stderr, "{\"persist_profile_us\": {");
+        for (int k = 0; k < kProfN; ++k)
+            fprintf(stderr, "%s\"%s\": %.1f", k ? ", " : "", names[k], (k == kProfIterations || k == kProfSteps) ? (double)p[k] : p[k] * 0.01);
+        fprintf(stderr, "}}\n");
+        hipFree(h->d_prof);
+    }
     delete h->persist2;
     delete h->persist3;
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -809,7 +832,8 @@ static PoseArr pose_arr(double* base, int V);
 static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src, int lo, int hi, const std::vector<int>& members,
                                 int iters, ClusterOut& o)
 {
-    if (h->persist) {
+    h->last_persist = h->persist && PersistSolver<PersistSe2>::fits(hi - lo, (int)members.size());
+    if (h->last_persist) {
         if (h->dim == 3) {
             IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
                                            h->h_from.data(), h->h_to.data(), iters));
@@ -827,12 +851,12 @@ static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src,
 }
 static PoseArr cluster_result2(const ipc_engine* h)
 {
-    if (!h->persist) return h->cluster->result();
+    if (!h->last_persist) return h->cluster->result();
     return h->persist2->result_in_second() ? h->persist2->dev().Xn : h->persist2->dev().X;
 }
 static const double* cluster_result3(const ipc_engine* h, int& ld)
 {
-    if (!h->persist) { ld = h->cluster3->ld(); return h->cluster3->result(); }
+    if (!h->last_persist) { ld = h->cluster3->ld(); return h->cluster3->result(); }
     ld = h->persist3->ld();
     return h->persist3->result_in_second() ? h->persist3->dev().Xn : h->persist3->dev().X;
 }
@@ -1219,7 +1243,10 @@ static int ensure_incremental(ipc_engine* h, const char* who)
             HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
         }
         if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; }
-        if (!h->persist3) { h->persist3 = new PersistSolver<PersistSe3>(); h->persist3->term_eps = h->term_eps; }
+        if (!h->persist3) {
+            h->persist3 = new PersistSolver<PersistSe3>(); h->persist3->term_eps = h->term_eps; h->persist3->d_prof = h->d_prof;
+            if (h->max_helpers >= 0) h->persist3->max_helpers = h->max_helpers;
+        }
         return IPC_OK;
     }
     if (!h->d_open) {
@@ -1231,7 +1258,10 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
     if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; }
-    if (!h->persist2) { h->persist2 = new PersistSolver<PersistSe2>(); h->persist2->term_eps = h->term_eps; }
+    if (!h->persist2) {
+        h->persist2 = new PersistSolver<PersistSe2>(); h->persist2->term_eps = h->term_eps; h->persist2->d_prof = h->d_prof;
+        if (h->max_helpers >= 0) h->persist2->max_helpers = h->max_helpers;
+    }
     return IPC_OK;
 }
 

@@ -12,12 +12,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    from ipc_amd import synth
-    from ipc_amd.consensus import IPC, Config
+    import bench
+    from ipc_amd.consensus import IPC
     which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "C1"
-    n_out = {"C1": 100, "C2": 1000}[which]
-    g = synth.inject_outliers(synth.intel_like(), n_out, seed=20260929)
-    cfg = Config(6.251, 50, 11.345, 100, 10.0)
+    g, cfg, _ = bench.build_workload(which)            # the bench's own workloads (same seeds as the committed fixtures)
     eng = IPC(g, cfg)
     order = eng.candidate_order()
     eng.reset()
@@ -48,7 +46,7 @@ def main():
     if "--cpu" in sys.argv:
         from oracle import oracle as O
         O.build()
-        inc = O.IncrementalIPC(2, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th,
+        inc = O.IncrementalIPC(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th,
                                cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base,
                                g.loop_ids, g.loop_meas, g.loop_info)
         t0 = time.perf_counter()
@@ -56,6 +54,7 @@ def main():
         out["cpu_oracle_incremental_s"] = time.perf_counter() - t0
         out["decisions_differing_from_cpu"] = int((acc_c != acc).sum())
     print(json.dumps(out))
+    eng.close()                                        # (IPC_PERSIST_PROF=1: the leader's phase clocks go to stderr here)
 
 
 if __name__ == "__main__":
