@@ -27,7 +27,7 @@ namespace ipc {
 
 constexpr int kPT = 512;                     // threads per workgroup (256 VGPRs per thread: the tile update and the SE3 phases need them)
 constexpr int kPSG = kPT / 256;              // 256-thread sub-groups (one 64 x 64 tile each)
-constexpr unsigned kSpinLimit = 1u << 23;    // polls before a barrier gives up (seconds): a lost workgroup must not hang the GPU
+constexpr unsigned kSpinLimit = 1u << 21;    // polls before a barrier gives up (seconds): a lost workgroup must not hang the GPU
 
 struct PersistCtl {                          // device memory, zeroed before every launch
     unsigned bar;                            // grid barrier: monotonic arrival counter
@@ -40,7 +40,8 @@ struct PersistOut {                          // result record (device, copied to
     double max_chi2, chi2_total, chi2_initial;
     int iterations, tries, flags, evals;
     int x_sel;                               // 1: the optimised poses sit in the second pose buffer
-    int error, pad0, pad1;
+    int error;                               // 1: a barrier timed out, 2: aborted by the host (speculative solve no longer needed)
+    int pad0, pad1;
 };
 
 struct PersistArgs {
@@ -49,6 +50,7 @@ struct PersistArgs {
     PersistCtl* ctl; PersistOut* out;
     double* dinv;                            // [n] reciprocal pivots of the factor
     unsigned long long* prof;                // optional [16] phase clocks of the leader (IPC_PERSIST_PROF=1), 100 MHz ticks
+    const int* abort_word; int launch_id;    // optional: host-mapped word; the solve gives up when it holds launch_id
 };
 
 // ---- LDS carve-up (doubles) -------------------------------------------------------------------------------
@@ -89,9 +91,11 @@ __device__ __forceinline__ bool grid_barrier(GridBar& gb)
     gb.target += (unsigned)gb.G;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(gb.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a few fast polls for the barriers inside the factorisation, then long naps: the helpers sit here through the
+        // leader's chain phases, and a chip full of pollers -- several solves in flight -- starves the memory fabric)
         unsigned spins = 0;
         while (__hip_atomic_load(gb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.target) {
-            __builtin_amdgcn_s_sleep(1);
+            if (spins < 48) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(64);
             if (++spins > kSpinLimit) { __hip_atomic_store(gb.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
@@ -745,6 +749,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     // g2o OptimizationAlgorithmDogleg::solve / SparseOptimizer::optimize, as cluster_dogleg() runs it from the host.
     // The scalar control arithmetic is kept unfused: cluster_dogleg() computes it on the CPU (x86-64, no FMA).
     PersistOut o{};
+    bool aborted = false;
     double currentChi = evaluate(false);
     o.chi2_initial = currentChi;
     {
@@ -754,6 +759,8 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     const int n_edges = L + nl;
     bool lastGN = false;
     for (int it = 0; it < P.iterations && alive; ++it) {
+        // a speculative solve whose starting state has been overtaken (the host committed an earlier candidate) stops here
+        if (P.abort_word && __hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == P.launch_id) { aborted = true; break; }
         double bb, bHb, hh, bh;
         const int info = linearize(bb, bHb, hh, bh);
         if (!alive) break;
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             o.max_chi2 = f != 0.0 ? __builtin_nan("") : m;
             o.chi2_total = currentChi;
             o.x_sel = n_commit & 1;
-            o.error = alive ? 0 : 1;
+            o.error = !alive ? 1 : (aborted ? 2 : 0);
             *P.out = o;
             prof_add(P.prof, kProfTotal, tk0);
         }
@@ -865,6 +872,8 @@ public:
     using Dev = typename T::Dev;
     double term_eps = 0.0;
     unsigned long long* d_prof = nullptr;       // optional device buffer [kProfN] the leader accumulates its phase clocks into
+    const int* d_abort_word = nullptr;          // optional host-mapped word (device address) and the id it is compared with
+    int launch_id = 0;
     int max_helpers = 39;                       // workgroups besides the leader (75 KB of LDS each)
 
     ~PersistSolver() { release(); }
@@ -883,8 +892,14 @@ public:
         D.S = d_S_; D.ldS = n + 1;
         D.partial = nullptr; D.scal = nullptr;
         tab_.build(lo, hi, members, from, to);
-        std::memcpy(h_tab_, tab_.host.data(), sizeof(int) * tab_.size());
-        IPC_CL_CHK(hipMemcpyAsync(d_int_, h_tab_, sizeof(int) * tab_.size(), hipMemcpyHostToDevice, st));
+        // (the staging buffer of this launch must outlive its copy: launches are enqueued without waiting for the
+        // previous one of this instance -- speculative solves get aborted and replaced -- so the buffers rotate)
+        tab_slot_ = (tab_slot_ + 1) % kTabSlots;
+        if (tab_used_[tab_slot_]) IPC_CL_CHK(hipEventSynchronize(ev_tab_[tab_slot_]));
+        std::memcpy(h_tab_[tab_slot_], tab_.host.data(), sizeof(int) * tab_.size());
+        IPC_CL_CHK(hipMemcpyAsync(d_int_, h_tab_[tab_slot_], sizeof(int) * tab_.size(), hipMemcpyHostToDevice, st));
+        IPC_CL_CHK(hipEventRecord(ev_tab_[tab_slot_], st));
+        tab_used_[tab_slot_] = true;
         D.lfrom = tab_.lfrom(d_int_); D.lto = tab_.lto(d_int_); D.lcand = tab_.lcand(d_int_);
         D.adj_ptr = tab_.adj_ptr(d_int_); D.adj_item = tab_.adj_item(d_int_);
         D.ev_ptr = tab_.ev_ptr(d_int_); D.ev_item = tab_.ev_item(d_int_);
@@ -894,7 +909,7 @@ public:
         const int tiles0 = n > 64 ? nt * (nt + 1) / 2 : 0;
         int G = 1 + std::min(max_helpers, (tiles0 + kPSG - 1) / kPSG);
         if (tiles0 == 0) G = 1;
-        PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_, d_prof};
+        PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_, d_prof, d_abort_word, launch_id};
         static bool attr_set = false;
         if (!attr_set) {
             IPC_CL_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_persist_kernel<T>),
@@ -918,9 +933,13 @@ public:
         out.max_chi2 = h_out_->max_chi2; out.chi2_total = h_out_->chi2_total; out.chi2_initial = h_out_->chi2_initial;
         out.iterations = h_out_->iterations; out.tries = h_out_->tries; out.flags = h_out_->flags; out.evals = h_out_->evals;
         x_sel_ = h_out_->x_sel;
-        return h_out_->error ? hipErrorLaunchFailure : hipSuccess;
+        aborted_ = h_out_->error == 2;
+        return h_out_->error == 1 ? hipErrorLaunchFailure : hipSuccess;
     }
+    bool aborted() const { return aborted_; }
 
+    // workspaces for chains up to L poses and nl loops, up front
+    hipError_t reserve(int L, int nl) { return ensure(L, nl); }
     const Dev& dev() const { return dev_; }
     bool result_in_second() const { return x_sel_ != 0; }
     // problems the leader's LDS staging cannot hold go to the host-driven solver
@@ -932,9 +951,14 @@ private:
     Dev dev_{};
     hipStream_t st_ = nullptr;
     int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
+    bool aborted_ = false;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
     int* d_int_ = nullptr;
-    int* h_tab_ = nullptr;
+    static constexpr int kTabSlots = 4;
+    int* h_tab_[kTabSlots] = {};
+    hipEvent_t ev_tab_[kTabSlots] = {};
+    bool tab_used_[kTabSlots] = {};
+    int tab_slot_ = 0;
     PersistCtl* d_ctl_ = nullptr;
     PersistOut *d_out_ = nullptr, *h_out_ = nullptr;
     LoopTables tab_;
@@ -942,9 +966,14 @@ private:
     void release()
     {
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_); hipFree(d_ctl_); hipFree(d_out_);
+        if (st_) hipStreamSynchronize(st_);
         if (h_out_) hipHostFree(h_out_);
-        if (h_tab_) hipHostFree(h_tab_);
-        d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; d_ctl_ = nullptr; d_out_ = h_out_ = nullptr; h_tab_ = nullptr;
+        for (int k = 0; k < kTabSlots; ++k) {
+            if (h_tab_[k]) hipHostFree(h_tab_[k]);
+            if (ev_tab_[k]) hipEventDestroy(ev_tab_[k]);
+            h_tab_[k] = nullptr; ev_tab_[k] = nullptr; tab_used_[k] = false;
+        }
+        d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; d_ctl_ = nullptr; d_out_ = h_out_ = nullptr;
         capL_ = capNl_ = 0;
     }
     hipError_t ensure(int L, int nl)
@@ -953,12 +982,17 @@ private:
             IPC_CL_CHK(hipHostMalloc(&h_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_ctl_, sizeof(PersistCtl)));
+            for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipEventCreateWithFlags(&ev_tab_[k], hipEventDisableTiming));
         }
         if (L > capL_ || nl > capNl_) {
-            const int nL = std::max(L, capL_), nN = std::max(nl, capNl_);
+            // (hipFree waits for the whole device, i.e. for every other solve in flight: grow in big steps -- the clusters
+            // of a run grow by one loop per accept)
+            const int nL = L > capL_ ? std::max(L, capL_ + capL_ / 2) : capL_;
+            const int nN = nl > capNl_ ? std::max(std::max(nl, 48), capNl_ + capNl_ / 2) : capNl_;
+            if (st_) IPC_CL_CHK(hipStreamSynchronize(st_));        // (a launch in flight still uses the old workspaces)
             hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_);
-            if (h_tab_) hipHostFree(h_tab_);
-            d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; h_tab_ = nullptr;
+            for (int k = 0; k < kTabSlots; ++k) { if (h_tab_[k]) hipHostFree(h_tab_[k]); h_tab_[k] = nullptr; tab_used_[k] = false; }
+            d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr;
             capL_ = capNl_ = 0;
             const size_t ld = (size_t)nL + 2, n = (size_t)T::kD * nN;
             IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (T::kEdgeDoubles * ld + ld + nN)));
@@ -966,7 +1000,7 @@ private:
             IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * 2 * (n + 1) * n));
             IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (n + kCB)));
             IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
-            IPC_CL_CHK(hipHostMalloc(&h_tab_, sizeof(int) * LoopTables::capacity(nL, nN)));
+            for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipHostMalloc(&h_tab_[k], sizeof(int) * LoopTables::capacity(nL, nN)));
             capL_ = nL; capNl_ = nN;
         }
         return hipSuccess;

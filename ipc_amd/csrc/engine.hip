@@ -553,7 +553,34 @@ struct ipc_engine {
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
     int max_helpers = -1;                              // IPC_PERSIST_HELPERS
+    // Speculative candidate window of the faithful mode (IPC_SPEC_WINDOW, default 8; 1 = off).  A rejected candidate
+    // leaves the state untouched (reference src/consensus.cpp:63-67), so the checks of the candidates that FOLLOW in
+    // the processing order can start from the same state before its verdict is known: up to `spec_window` cluster
+    // solves run concurrently, each in its own persistent launch on its own stream.  A result is only ever used if
+    // no commit happened since its launch (state_version); on an accept the others are told to stop and are redone.
+    struct SpecSlot {
+        PersistSolver<PersistSe2>* s2 = nullptr;
+        PersistSolver<PersistSe3>* s3 = nullptr;
+        hipStream_t st = nullptr;
+        int cand = -1;                                 // candidate whose solve is in flight / waiting to be read, -1: none
+        unsigned long long version = 0;                // state_version at launch
+        int launch_id = 0;
+        int lo = 0, hi = 0, nclu = 0;
+        double th = 0.0;
+        unsigned long long commit_seen = 0;            // commits the stream is ordered behind
+    };
+    std::vector<SpecSlot> slots;
+    int spec_window = 4;
+    unsigned long long state_version = 1, commit_count = 0;
+    hipEvent_t ev_commit = nullptr;
+    int* h_abort = nullptr;                            // host-mapped: one word per slot, the launch id to give up
+    int* d_abort = nullptr;
+    int next_launch_id = 1;
+    std::vector<int> pos_of;                           // candidate -> position in the processing order
+    long spec_hits = 0, spec_launches = 0, spec_wasted = 0;
 };
+
+static int spec_quiesce(ipc_engine* h, bool state_changes);
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
@@ -566,6 +593,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (n_vertices < 2 || !odom_meas || !odom_info || !params)
         return fail(IPC_ERR_ARG, "ipc_create: need >= 2 vertices and non-NULL arrays");
     if (!(params->s_factor > 0)) return fail(IPC_ERR_ARG, "ipc_create: s_factor must be > 0");
+    // The speculative window of the faithful mode runs one persistent launch per stream; streams that share a hardware
+    // queue run their kernels one after the other, and the runtime's default is 4 queues.  Only effective when this is
+    // the process's first HIP call (otherwise export GPU_MAX_HW_QUEUES before starting; ipc_amd/capi.py does).
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(IPC_ERR_ARG, "ipc_create: device %d of %d", device, ndev);
@@ -587,6 +618,11 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         }
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
+    {   // window: as many solves in flight as there are hardware queues to run them side by side (IPC_SPEC_WINDOW overrides)
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        h->spec_window = (q && atoi(q) >= 9) ? 8 : 4;
+    }
+    if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) h->spec_window = std::max(1, std::min(32, atoi(sw))); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
         else if (*cm && strcmp(cm, "persist")) { delete h; return fail(IPC_ERR_ARG, "IPC_CLUSTER_MODE must be 'persist' or 'host'"); }
@@ -671,6 +707,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
 {
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
+    spec_quiesce(h, true);
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
@@ -691,6 +728,16 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         fprintf(stderr, "}}\n");
         hipFree(h->d_prof);
     }
+    for (auto& sl : h->slots) {
+        if (sl.st) hipStreamSynchronize(sl.st);
+        delete sl.s2; delete sl.s3;
+        if (sl.st) hipStreamDestroy(sl.st);
+    }
+    if (h->d_prof || getenv("IPC_SPEC_STATS"))
+        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"launches\": %ld, \"cache_hits\": %ld, \"discarded\": %ld}}\n",
+                h->spec_window, h->spec_launches, h->spec_hits, h->spec_wasted);
+    if (h->ev_commit) hipEventDestroy(h->ev_commit);
+    if (h->h_abort) hipHostFree(h->h_abort);
     delete h->persist2;
     delete h->persist3;
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -711,6 +758,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     if (!h) return fail(IPC_ERR_ARG, "ipc_set_candidates: NULL handle");
     if (n < 0 || (n > 0 && (!ids || !meas || !info))) return fail(IPC_ERR_ARG, "ipc_set_candidates: bad arrays");
     HIPCHK(hipSetDevice(h->device));
+    if (int rc = spec_quiesce(h, true)) return rc;
     free_candidates(h);
     h->last_cells = 0;
     h->ev_valid = false;
@@ -735,6 +783,8 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     std::iota(h->order.begin(), h->order.end(), 0);
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
     h->N = n;
+    h->pos_of.assign(n, 0);
+    for (int q = 0; q < n; ++q) h->pos_of[h->order[q]] = q;
     h->h_from = from; h->h_to = to;
     h->cstride = (n + 63) & ~63;
     const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21, nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
@@ -1277,8 +1327,199 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_reset: NULL handle");
     if (int rc = ensure_incremental(h, "ipc_incremental_reset")) return rc;
+    if (int rc = spec_quiesce(h, true)) return rc;
     HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
     h->cns.clear();
+    return IPC_OK;
+}
+
+// computeIndependentSubgraph (src/consensus.cpp:124-171) for candidate k against the current consensus set: absorb
+// accepted edges whose id interval overlaps the growing extremes with positive length, until nothing new is found;
+// then the threshold / iteration base of :50-52 and the x5 rule of consensus_utils.cpp:12-13.  members = the absorbed
+// edges in the order they were found, then k (:56).
+struct ClusterSpec { int lo, hi, nclu, iters; double th; std::vector<int> members; };
+static ClusterSpec cluster_of(const ipc_engine* h, int k)
+{
+    ClusterSpec c;
+    c.lo = h->h_lo[k]; c.hi = h->h_hi[k];
+    std::vector<char> inc(h->cns.size(), 0);
+    bool found = true;
+    while (found) {
+        found = false;
+        for (size_t q = 0; q < h->cns.size(); ++q) {
+            if (inc[q]) continue;
+            const int e = h->cns[q];
+            if (std::min(h->h_hi[e], c.hi) - std::max(h->h_lo[e], c.lo) <= 0) continue;
+            c.lo = std::min(c.lo, h->h_lo[e]); c.hi = std::max(c.hi, h->h_hi[e]);
+            inc[q] = 1; found = true;
+            c.members.push_back(e);
+        }
+    }
+    const bool intersection = !c.members.empty();                             // :50-52
+    c.th = intersection ? h->prm.slow_reject_th : h->prm.fast_reject_th;
+    c.iters = intersection ? h->prm.slow_reject_iter_base : h->prm.fast_reject_iter_base;
+    c.nclu = (int)c.members.size();
+    c.members.push_back(k);                                                   // :56
+    if ((c.hi - c.lo) + (int)c.members.size() > 100) c.iters *= 5;            // consensus_utils.cpp:12-13
+    return c;
+}
+
+// IPC::agreementCheck's accept branch (src/consensus.cpp:69-71): the optimised window replaces the current poses, the
+// tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71), k joins the set.  Enqueued on `st`.
+static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
+{
+    if (h->dim == 3) {
+        HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, X3, sizeof(double) * ld3, sizeof(double) * (hi - lo + 1), 12,
+                                hipMemcpyDeviceToDevice, st));
+        if (hi + 1 < h->V)
+            hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, h->d_cur);
+    } else {
+        const double* xs[5] = {X2->x, X2->y, X2->th, X2->c, X2->s};
+        for (int f = 0; f < 5; ++f)
+            HIPCHK(hipMemcpyAsync(h->d_cur + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1), hipMemcpyDeviceToDevice, st));
+        if (hi + 1 < h->V)
+            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, h->d_cur);
+    }
+    HIPCHK(hipGetLastError());
+    h->cns.push_back(k);
+    return IPC_OK;
+}
+
+// ---- speculative window ---------------------------------------------------------------------------------
+static int spec_ensure(ipc_engine* h)
+{
+    if (!h->slots.empty()) return IPC_OK;
+    HIPCHK(hipHostMalloc(&h->h_abort, sizeof(int) * 64, hipHostMallocMapped));
+    std::memset(h->h_abort, 0, sizeof(int) * 64);
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_abort), h->h_abort, 0));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_commit, hipEventDisableTiming));
+    h->slots.resize(h->spec_window);
+    // every workgroup of every solve in flight must be resident (they meet at grid barriers) and one workgroup fills a
+    // CU's register file: the window's workgroups may not exceed the CUs
+    const int helper_cap = std::max(0, h->n_cu / h->spec_window - 1);
+    for (int q = 0; q < h->spec_window; ++q) {
+        ipc_engine::SpecSlot& sl = h->slots[q];
+        HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        if (h->dim == 3) {
+            sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
+            sl.s3->d_abort_word = h->d_abort + q;
+            if (h->max_helpers >= 0) sl.s3->max_helpers = h->max_helpers;
+            sl.s3->max_helpers = std::min(sl.s3->max_helpers, helper_cap);
+            HIPCHK(sl.s3->reserve(h->V - 1, std::min(h->N, 48)));
+        } else {
+            sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
+            sl.s2->d_abort_word = h->d_abort + q;
+            if (h->max_helpers >= 0) sl.s2->max_helpers = h->max_helpers;
+            sl.s2->max_helpers = std::min(sl.s2->max_helpers, helper_cap);
+            HIPCHK(sl.s2->reserve(h->V - 1, std::min(h->N, 48)));
+        }
+    }
+    return IPC_OK;
+}
+
+// every solve in flight started from a state that no longer exists: tell it to stop, forget its result
+static void spec_invalidate(ipc_engine* h, int keep_slot)
+{
+    for (size_t q = 0; q < h->slots.size(); ++q) {
+        ipc_engine::SpecSlot& sl = h->slots[q];
+        if ((int)q == keep_slot || sl.cand < 0) continue;
+        __atomic_store_n(&h->h_abort[q], sl.launch_id, __ATOMIC_RELEASE);
+        sl.cand = -1;
+        ++h->spec_wasted;
+    }
+    ++h->state_version;
+}
+
+static int spec_launch(ipc_engine* h, int q, int k)
+{
+    ipc_engine::SpecSlot& sl = h->slots[q];
+    const ClusterSpec c = cluster_of(h, k);
+    sl.cand = k; sl.version = h->state_version; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th;
+    sl.launch_id = h->next_launch_id++;
+    if (h->next_launch_id == 0x7fffffff) h->next_launch_id = 1;
+    if (sl.commit_seen != h->commit_count) {            // the poses it starts from are those of the last commit
+        HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
+        sl.commit_seen = h->commit_count;
+    }
+    ++h->spec_launches;
+    if (h->dim == 3) {
+        sl.s3->launch_id = sl.launch_id;
+        HIPCHK(sl.s3->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V, c.lo, c.hi, c.members,
+                             h->h_from.data(), h->h_to.data(), c.iters));
+    } else {
+        sl.s2->launch_id = sl.launch_id;
+        HIPCHK(sl.s2->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V, c.lo, c.hi, c.members,
+                             h->h_from.data(), h->h_to.data(), c.iters));
+    }
+    return IPC_OK;
+}
+
+static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
+{
+    if (int rc = spec_ensure(h)) return rc;
+    const int B = (int)h->slots.size();
+    auto find = [&](int cand) {
+        for (int q = 0; q < B; ++q)
+            if (h->slots[q].cand == cand && h->slots[q].version == h->state_version) return q;
+        return -1;
+    };
+    auto free_slot = [&]() {
+        for (int q = 0; q < B; ++q) if (h->slots[q].cand < 0) return q;
+        return -1;
+    };
+    int qk = find(k);
+    if (qk >= 0) ++h->spec_hits;
+    else {
+        qk = free_slot();
+        if (qk < 0) {                                   // window full of other candidates (a caller off the processing order)
+            spec_invalidate(h, -1);
+            qk = 0;
+        }
+        if (int rc = spec_launch(h, qk, k)) return rc;
+    }
+    // keep the window full: the candidates that follow k in the processing order, from the same state
+    for (int ahead = 1; ahead < B; ++ahead) {
+        const int p = h->pos_of[k] + ahead;
+        if (p >= h->N) break;
+        const int c = h->order[p];
+        if (find(c) >= 0) continue;
+        const int q = free_slot();
+        if (q < 0) break;
+        if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->cns.size() + 1)) break;
+        if (int rc = spec_launch(h, q, c)) return rc;
+    }
+    ipc_engine::SpecSlot& sl = h->slots[qk];
+    ClusterOut o;
+    HIPCHK(h->dim == 3 ? sl.s3->wait(o) : sl.s2->wait(o));
+    const bool agree = !(o.max_chi2 > sl.th);                                 // consensus_utils.cpp:17-21
+    const int lo = sl.lo, hi = sl.hi, nclu = sl.nclu;
+    sl.cand = -1;
+    if (agree) {                                                              // :69-71
+        spec_invalidate(h, -1);
+        if (h->dim == 3) {
+            const double* res = sl.s3->result_in_second() ? sl.s3->dev().Xn : sl.s3->dev().X;
+            if (int rc = commit_accept(h, sl.st, k, lo, hi, nullptr, res, sl.s3->ld())) return rc;
+        } else {
+            const PoseArr X = sl.s2->result_in_second() ? sl.s2->dev().Xn : sl.s2->dev().X;
+            if (int rc = commit_accept(h, sl.st, k, lo, hi, &X, nullptr, 0)) return rc;
+        }
+        HIPCHK(hipEventRecord(h->ev_commit, sl.st));
+        ++h->commit_count;
+        sl.commit_seen = h->commit_count;
+    }
+    *agrees = agree ? 1 : 0;
+    fill_info(info, lo, hi, nclu, o);
+    return IPC_OK;
+}
+
+// the poses / the set are about to be read or edited from outside the window: nothing in flight may outlive that
+static int spec_quiesce(ipc_engine* h, bool state_changes)
+{
+    if (h->slots.empty()) return IPC_OK;
+    if (state_changes) spec_invalidate(h, -1);
+    if (h->commit_count) HIPCHK(hipEventSynchronize(h->ev_commit));
+    if (state_changes)
+        for (auto& sl : h->slots) HIPCHK(hipStreamSynchronize(sl.st));
     return IPC_OK;
 }
 
@@ -1288,66 +1529,26 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
     if (h->N == 0) return fail(IPC_ERR_STATE, "ipc_agreement_check: no candidates set");
     if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_agreement_check: candidate %d of %d", k, h->N);
     if (int rc = ensure_incremental(h, "ipc_agreement_check")) return rc;
-    // computeIndependentSubgraph (src/consensus.cpp:124-171): absorb accepted edges whose id interval
-    // overlaps the growing extremes with positive length, until nothing new is found
-    int lo = h->h_lo[k], hi = h->h_hi[k];
-    std::vector<char> inc(h->cns.size(), 0);
-    std::vector<int> members;
-    bool found = true;
-    while (found) {
-        found = false;
-        for (size_t c = 0; c < h->cns.size(); ++c) {
-            if (inc[c]) continue;
-            const int e = h->cns[c];
-            if (std::min(h->h_hi[e], hi) - std::max(h->h_lo[e], lo) <= 0) continue;
-            lo = std::min(lo, h->h_lo[e]); hi = std::max(hi, h->h_hi[e]);
-            inc[c] = 1; found = true;
-            members.push_back(e);
-        }
-    }
-    const bool intersection = !members.empty();                               // :50-52
-    const double th = intersection ? h->prm.slow_reject_th : h->prm.fast_reject_th;
-    int iters = intersection ? h->prm.slow_reject_iter_base : h->prm.fast_reject_iter_base;
-    const int nclu = (int)members.size();
-    members.push_back(k);                                                     // :56
-    if ((hi - lo) + (int)members.size() > 100) iters *= 5;                   // consensus_utils.cpp:12-13
+    if (h->persist && h->spec_window > 1 && PersistSolver<PersistSe2>::fits(h->V, (int)h->cns.size() + 1))
+        return agreement_check_speculative(h, k, agrees, info);
+    if (int rc = spec_quiesce(h, true)) return rc;
+    const ClusterSpec c = cluster_of(h, k);
     ClusterOut o;
-    if (h->dim == 3) {
-        HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, lo, hi, members, iters, o));
-        const bool agree3 = !(o.max_chi2 > th);
-        if (agree3) {
-            int rld = 0;
-            const double* res = cluster_result3(h, rld);
-            HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, res, sizeof(double) * rld,
-                                    sizeof(double) * (hi - lo + 1), 12, hipMemcpyDeviceToDevice, h->own_stream));
-            if (hi + 1 < h->V)
-                hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, h->own_stream, h->V, hi, h->d_chain,
-                                   h->estride, h->d_cur);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(h->own_stream));
-            h->cns.push_back(k);
-        }
-        *agrees = agree3 ? 1 : 0;
-        fill_info(info, lo, hi, nclu, o);
-        return IPC_OK;
-    }
-    HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, lo, hi, members, iters, o));
-    const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
+    HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, c.lo, c.hi, c.members, c.iters, o));
+    const bool agree = !(o.max_chi2 > c.th);                                  // consensus_utils.cpp:17-21
     if (agree) {                                                              // :69-71
-        const PoseArr X = cluster_result2(h);
-        const double* xs[5] = {X.x, X.y, X.th, X.c, X.s};
-        for (int f = 0; f < 5; ++f)
-            HIPCHK(hipMemcpyAsync(h->d_cur + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1),
-                                  hipMemcpyDeviceToDevice, h->own_stream));
-        if (hi + 1 < h->V)
-            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, h->own_stream, h->V, hi, h->d_chain,
-                               h->estride, h->d_cur);
-        HIPCHK(hipGetLastError());
+        int rld = 0;
+        if (h->dim == 3) {
+            const double* res = cluster_result3(h, rld);
+            if (int rc = commit_accept(h, h->own_stream, k, c.lo, c.hi, nullptr, res, rld)) return rc;
+        } else {
+            const PoseArr X = cluster_result2(h);
+            if (int rc = commit_accept(h, h->own_stream, k, c.lo, c.hi, &X, nullptr, 0)) return rc;
+        }
         HIPCHK(hipStreamSynchronize(h->own_stream));
-        h->cns.push_back(k);
     }
     *agrees = agree ? 1 : 0;
-    fill_info(info, lo, hi, nclu, o);
+    fill_info(info, c.lo, c.hi, c.nclu, o);
     return IPC_OK;
 }
 
@@ -1369,6 +1570,7 @@ extern "C" int ipc_remove_from_consensus(ipc_engine_t* h, int k, int* removed)
 {
     if (!h || !removed) return fail(IPC_ERR_ARG, "ipc_remove_from_consensus: NULL argument");
     if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_remove_from_consensus: candidate %d of %d", k, h->N);
+    if (int rc = spec_quiesce(h, true)) return rc;
     *removed = 0;
     for (auto it = h->cns.begin(); it != h->cns.end(); ++it) {
         if (h->h_lo[*it] != h->h_lo[k] || h->h_hi[*it] != h->h_hi[k]) continue;
@@ -1383,6 +1585,7 @@ extern "C" int ipc_add_to_consensus(ipc_engine_t* h, int k)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_add_to_consensus: NULL handle");
     if (k < 0 || k >= h->N) return fail(IPC_ERR_ARG, "ipc_add_to_consensus: candidate %d of %d", k, h->N);
+    if (int rc = spec_quiesce(h, true)) return rc;
     for (int e : h->cns)
         if (h->h_lo[e] == h->h_lo[k] && h->h_hi[e] == h->h_hi[k]) return IPC_OK;
     h->cns.push_back(k);
@@ -1418,6 +1621,7 @@ extern "C" int ipc_current_poses(ipc_engine_t* h, double* poses_out)
 {
     if (!h || !poses_out) return fail(IPC_ERR_ARG, "ipc_current_poses: NULL argument");
     if (int rc = ensure_incremental(h, "ipc_current_poses")) return rc;
+    if (int rc = spec_quiesce(h, false)) return rc;
     if (h->dim == 3) return download_poses3(h, h->d_cur, h->V, h->V, poses_out);
     return download_poses(h, pose_arr(h->d_cur, h->V), h->V, poses_out);
 }

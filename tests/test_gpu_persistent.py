@@ -20,17 +20,19 @@ REL = 1e-5
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _engine(g, cfg, mode):
+def _engine(g, cfg, mode, **env):
     from ipc_amd.consensus import IPC
-    old = os.environ.get("IPC_CLUSTER_MODE")
-    os.environ["IPC_CLUSTER_MODE"] = mode
+    env = dict(env, IPC_CLUSTER_MODE=mode)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
     try:
         return IPC(g, cfg, device=0)
     finally:
-        if old is None:
-            del os.environ["IPC_CLUSTER_MODE"]
-        else:
-            os.environ["IPC_CLUSTER_MODE"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 def _run(eng, order):
@@ -135,6 +137,47 @@ def test_persistent_equals_host_driven_se3():
     assert max(r[3] for r in rp) >= 40
     _assert_bitwise(rp, rh)
     assert np.array_equal(ep.current_poses().view(np.uint64), eh.current_poses().view(np.uint64))
+
+
+@pytest.mark.parametrize("window", [2, 8])
+def test_speculative_window_is_exact(window):
+    """The candidates that follow a check in the processing order are solved ahead from the same state, concurrently
+    (one persistent launch each); a result is used only if no accept intervened.  Whatever the window, every check
+    returns the bits of the one-at-a-time run -- also for a caller that leaves the processing order."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    g = synth._se2_graph(400, 24, seed=81, laps=3.0, name="inc")
+    g = synth.inject_outliers(g, 40, seed=2)
+    cfg = Config()
+    e1, ew = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1), _engine(g, cfg, "persist", IPC_SPEC_WINDOW=window)
+    order = e1.candidate_order()
+    _assert_bitwise(_run(e1, order), _run(ew, order))
+    assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
+    assert np.array_equal(e1.getMaxConsensusSet(), ew.getMaxConsensusSet())
+    scrambled = np.concatenate([order[::3], order[1::3][::-1], order[2::3]])
+    _assert_bitwise(_run(e1, scrambled), _run(ew, scrambled))
+    assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
+    # set editing in the middle of a run throws the window away
+    for e in (e1, ew):
+        e.reset()
+        for k in order[:20]:
+            e.agreementCheck(int(k))
+        cs = list(e.getMaxConsensusSet())
+        e.removeEdgeFromCnS(cs[0])
+    ra = [(e1.agreementCheck(int(k), with_info=True)) for k in order[20:40]]
+    rb = [(ew.agreementCheck(int(k), with_info=True)) for k in order[20:40]]
+    for (oka, ia), (okb, ib) in zip(ra, rb):
+        assert oka == okb and ia.iterations == ib.iterations
+        assert np.float64(ia.max_chi2).tobytes() == np.float64(ib.max_chi2).tobytes()
+
+
+def test_speculative_window_se3_is_exact():
+    import bench
+    g, cfg, _ = bench.build_workload("C4s")
+    e1, ew = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1), _engine(g, cfg, "persist", IPC_SPEC_WINDOW=6)
+    order = e1.candidate_order()
+    _assert_bitwise(_run(e1, order), _run(ew, order))
+    assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
 
 
 def test_final_map_persistent_equals_host_driven():
