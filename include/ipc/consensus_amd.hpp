@@ -1,15 +1,20 @@
 // consensus_amd.hpp -- drop-in for the reference's include/ipc/consensus.hpp (class surface of
 // reference include/ipc/consensus.hpp:5-33, behaviour of src/consensus.cpp) on top of libipc_amd.so.
 //
-// Put this header (and include/ipc_amd.h) on the reference's include path, include it instead of
-// "ipc/consensus.hpp", drop src/consensus.cpp from the build and link -lipc_amd: ipc_tester_2D/3D and
-// src/simulation.cpp compile unchanged -- `IPC<EDGE, VERTEX> ipc(problem, cfg); ipc.agreementCheck(e);
-// ipc.getMaxConsensusSet()` keep their meaning.  The g2o optimizer still owns the graph; the engine
-// keeps its own copy of the odometry chain, the candidate edges it has seen and the pose state on
-// the GPU.
+// Put this repo's include/ directory in FRONT of the reference's on the include path (include/ipc/consensus.hpp here
+// is a one-line shim onto this header, so the testers' and src/simulation.cpp's literal `#include "ipc/consensus.hpp"`
+// resolves to it), drop src/consensus.cpp from the build, keep src/consensus_utils.cpp and src/utils.cpp, link
+// -lipc_amd: ipc_tester_2D/3D and src/simulation.cpp compile unchanged -- `IPC<EDGE, VERTEX> ipc(problem, cfg);
+// ipc.agreementCheck(e); ipc.getMaxConsensusSet()` keep their meaning.  The g2o optimizer still owns the graph; the
+// engine keeps its own copy of the odometry chain, the candidate edges it has seen and the pose state on the GPU.
 //
-// What the reference header pulls in is expected from "ipc/utils.hpp" (Config, getProblemOdom,
-// cmpEdgesID; reference include/ipc/utils.hpp:22-38,98-121) -- unchanged reference code.
+// Like the reference's header (include/ipc/consensus.hpp:3) this one pulls in "ipc/consensus_utils.hpp" -- unchanged
+// reference code, which the harness itself needs (propagateGuess, src/simulation.cpp:52) -- and through it
+// "ipc/utils.hpp" (Config, getProblemOdom, cmpEdgesID; reference include/ipc/utils.hpp:22-38,98-121).  The constructor
+// has the side effects on the caller's graph the reference's has: the odometry information is multiplied by s_factor
+// IN PLACE (robustifyVoters, src/consensus.cpp:21 -- src/simulation.cpp:56 divides it back before the final
+// optimize(1000)) and the vertices are set to the open-loop guess (propagateGuess, :23), both by the reference's own
+// functions.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -18,7 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "ipc/utils.hpp"
+#include "ipc/consensus_utils.hpp"
 #include "ipc_amd.h"
 
 namespace ipc_amd_adapter {
@@ -66,7 +71,11 @@ public:
         }
         const ipc_params_t p{cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th,
                              cfg.slow_reject_iter_base, cfg.s_factor};
+        // (the engine gets the information as the file has it and scales its own copy)
         chk(ipc_create(EDGE::Dimension == 3 ? 2 : 3, (int)odom.size() + 1, meas.data(), info.data(), &p, device, &_h));
+        // the reference constructor's effects on the caller's graph, by the reference's own functions
+        robustifyVoters<EDGE>(0, (int)odom.size(), cfg.s_factor, odom);                         // src/consensus.cpp:21
+        propagateGuess<EDGE, VERTEX>(open_loop_problem, 0, (int)odom.size(), odom);            // src/consensus.cpp:23
     }
     // reference src/consensus.cpp:35-40 (clears the caller's graph, as the reference does)
     ~IPC()
@@ -77,15 +86,16 @@ public:
     IPC(const IPC&) = delete;
     IPC& operator=(const IPC&) = delete;
 
-    // The candidate list of the run (reference src/simulation.cpp:24-26: the harness's `loops`, any
-    // order): uploads it once.  Optional -- agreementCheck() registers unseen edges by itself, at the
-    // price of a re-upload (which resets the engine's consensus state, so it replays the accepted
-    // edges; call this first to avoid that).
+    // The candidate list of the run (reference src/simulation.cpp:24-26: the harness's `loops`, any order), uploaded
+    // once.  Optional: agreementCheck() appends an edge the engine has not seen (ipc_append_candidate: the consensus
+    // set and the poses stay as they are), but only a list announced up front lets the engine work ahead of the
+    // caller (speculative window over the candidates that follow in the processing order).
     void setCandidates(const std::vector<EDGE*>& candidates)
     {
         _cands = candidates;
         _index_of.clear();
         for (size_t k = 0; k < _cands.size(); ++k) _index_of[_cands[k]] = (int)k;
+        _max_consensus_set.clear();
         upload();
     }
 
@@ -165,19 +175,20 @@ private:
     {
         auto it = _index_of.find(e);
         if (it != _index_of.end()) return it->second;
-        // an edge the engine has not seen: append, re-upload, replay the accepted edges so that the
-        // pose state and the consensus set are what they were (same order => same state)
+        // an edge object the engine has not seen.  The reference identifies edges by their vertex ids
+        // (src/consensus.cpp:84-87,106-109): one that joins the same pair as a known candidate IS that candidate
+        const int a = e->vertices()[0]->id(), b = e->vertices()[1]->id();
+        for (size_t k = 0; k < _cands.size(); ++k)
+            if (_cands[k]->vertices()[0]->id() == a && _cands[k]->vertices()[1]->id() == b) { _index_of[e] = (int)k; return (int)k; }
+        // a new one: appended, nothing is replayed
+        std::vector<double> meas, info;
+        const int ids[2] = {a, b};
+        ipc_amd_adapter::pack_measurement(*e, meas, Dim{});
+        ipc_amd_adapter::pack_information_upper(*e, info);
+        int k = -1;
+        chk(ipc_append_candidate(_h, ids, meas.data(), info.data(), &k));
         _cands.push_back(e);
-        const int k = (int)_cands.size() - 1;
         _index_of[e] = k;
-        upload();
-        const std::vector<EDGE*> accepted = _max_consensus_set;
-        _max_consensus_set.clear();
-        for (EDGE* a : accepted) {
-            int ok = 0;
-            chk(ipc_agreement_check(_h, _index_of.at(a), &ok, nullptr));
-            if (ok) _max_consensus_set.push_back(a);
-        }
         return k;
     }
     void refresh_set()

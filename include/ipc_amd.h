@@ -84,6 +84,12 @@ int ipc_destroy(ipc_engine_t* h);
 int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* meas,
                        const double* info);
 
+/* One more candidate at the END of the list (index N), without touching the incremental state: the consensus set
+ * (candidate indices) and the current poses stay what they are.  For a harness that meets its loop closures one by one
+ * (reference src/simulation.cpp:34-47 hands IPC::agreementCheck edges it has never announced).  *index_out = the new
+ * candidate's index. */
+int ipc_append_candidate(ipc_engine_t* h, const int* ids, const double* meas, const double* info, int* index_out);
+
 /* cmpTime processing order (host copy, N ints). */
 int ipc_candidate_order(ipc_engine_t* h, int* order_out);
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
-    "ipc_debug_dense_solve",
+    "ipc_debug_dense_solve", "ipc_append_candidate",
 ]
 
 
@@ -83,6 +83,7 @@ def load():
     lib.ipc_create.argtypes = [ip, ip, vp, vp, C.POINTER(Params), ip, C.POINTER(vp)]
     lib.ipc_destroy.argtypes = [vp]
     lib.ipc_set_candidates.argtypes = [vp, ip, vp, vp, vp]
+    lib.ipc_append_candidate.argtypes = [vp, vp, vp, vp, C.POINTER(ip)]
     lib.ipc_candidate_order.argtypes = [vp, vp]
     lib.ipc_initial_poses.argtypes = [vp, vp]
     lib.ipc_rows_per_rank.argtypes = [ip, ip]

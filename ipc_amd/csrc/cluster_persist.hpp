@@ -508,30 +508,68 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
     return info;
 }
 
-// L^T x = y (y = row n of the factor), workgroup 0 only: dense_chol.hpp::chol_backsolve with sc1 reads
+// L^T x = y (y = row n of the factor), workgroup 0 only: dense_chol.hpp::chol_backsolve's sums in its order, but the
+// factor's entries of block column kb-1 (4 columns per wave, the first 768 rows below the block; its diagonal block;
+// its right-hand side) are requested BEFORE the triangle of block column kb is solved -- they do not depend on x --
+// so a step costs its arithmetic, not a round trip to memory per phase.  x also lives in LDS while it fits.
 __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x, double* lds)
 {
+    constexpr int NW = kPT / 64, CPW = kCB / NW, MAXM = 12, DPT = kCB * kCB / kPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
     double* t = lds + kLdsDinv;
+    double* xs = lds + kLdsR;
+    const bool x_in_lds = n <= kPSG * 2 * kLdsPanel;
     const int ld = n + 1;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31;
     const int nblk = (n + kCB - 1) / kCB;
+    double pre[CPW][MAXM], dpre[DPT], ypre = 0.0;
+    auto prefetch = [&](int kb) {
+        const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const int c = wave + q * NW;
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                const int r = k1 + lane + 64 * m;
+                pre[q][m] = ld_shared(&Lf[(c < nb && r < n) ? (size_t)(k0 + c) * ld + r : (size_t)0]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
+            dpre[q] = ld_shared(&Lf[(r < nb && c < nb && r >= c) ? (size_t)(k0 + c) * ld + k0 + r : (size_t)0]);
+        }
+        ypre = ld_shared(&Lf[l < nb ? (size_t)(k0 + l) * ld + n : (size_t)0]);
+    };
+    prefetch(nblk - 1);
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
-        for (int c = wave; c < nb; c += kPT / 64) {
-            double acc = 0.0;
-            for (int r = k1 + lane; r < n; r += 64) acc += ld_shared(&Lf[(size_t)(k0 + c) * ld + r]) * x[r];
-            acc = wave_sum(acc);
-            if (lane == 0) t[c] = acc;
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const int c = wave + q * NW;
+            if (c < nb) {                                     // (wave-uniform)
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < MAXM; ++m) {
+                    const int r = k1 + lane + 64 * m;
+                    const double xr = x_in_lds ? xs[r < n ? r : 0] : x[r < n ? r : 0];
+                    if (r < n) acc += pre[q][m] * xr;
+                }
+                for (int r = k1 + lane + 64 * MAXM; r < n; r += 64) acc += ld_shared(&Lf[(size_t)(k0 + c) * ld + r]) * x[r];
+                acc = wave_sum(acc);
+                t[c] = acc;                                   // (uniform: every lane stores it)
+            }
         }
-        for (int idx = tid; idx < kCB * kCB; idx += kPT) {
-            const int r = idx % kCB, c = idx / kCB;
-            D[r][c] = (r < nb && c < nb && r >= c) ? ld_shared(&Lf[(size_t)(k0 + c) * ld + k0 + r]) : (r == c ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
+            D[r][c] = (r < nb && c < nb && r >= c) ? dpre[q] : (r == c ? 1.0 : 0.0);
         }
+        const double ycur = ypre;
+        if (kb > 0) prefetch(kb - 1);
         __syncthreads();
         if (wave == 0) {
-            const int l = lane & 31;
-            double v = l < nb ? ld_shared(&Lf[(size_t)(k0 + l) * ld + n]) - t[l] : 0.0;
+            double v = l < nb ? ycur - t[l] : 0.0;
             const double dinv = 1.0 / D[l][l];
             double col[kCB];
 #pragma unroll
@@ -541,7 +579,10 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
                 const double xr = read_lane(v, r) * read_lane(dinv, r);
                 v = l == r ? xr : (l < r ? fma(-col[r], xr, v) : v);
             }
-            if (lane < nb) x[k0 + lane] = v;
+            if (lane < nb) {
+                x[k0 + lane] = v;
+                if (x_in_lds) xs[k0 + lane] = v;
+            }
         }
         __syncthreads();
     }

@@ -521,6 +521,7 @@ struct ipc_engine {
     int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
     int* d_live = nullptr;                             // set-max: candidates with a set diagonal bit, in processing order
     std::vector<int> order, h_lo, h_hi;
+    std::vector<int> h_cand_ids; std::vector<double> h_cand_meas, h_cand_info;   // raw candidate records in file order
     // plan / results of the last solve
     unsigned* d_counters = nullptr;   // [2*(kMaxBins+1)]
     unsigned* d_offsets = nullptr;
@@ -753,29 +754,40 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     return IPC_OK;
 }
 
-extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* meas, const double* info)
+// Uploads the candidate list (file order).  preserve_state: the list only GREW at its end (ipc_append_candidate), so the
+// consensus set (candidate indices) and the current poses stay what they are; otherwise the incremental state is reset.
+static int upload_candidates(ipc_engine* h, int n, const int* ids, const double* meas, const double* info, bool preserve_state)
 {
-    if (!h) return fail(IPC_ERR_ARG, "ipc_set_candidates: NULL handle");
-    if (n < 0 || (n > 0 && (!ids || !meas || !info))) return fail(IPC_ERR_ARG, "ipc_set_candidates: bad arrays");
+    for (int k = 0; k < n; ++k) {
+        const int f = ids[2 * k], t = ids[2 * k + 1];
+        if (f < 0 || t < 0 || f >= h->V || t >= h->V)
+            return fail(IPC_ERR_ARG, "candidate %d joins vertex %d-%d outside 0..%d", k, f, t, h->V - 1);
+        if (std::abs(f - t) < 2)
+            return fail(IPC_ERR_ARG, "candidate %d joins adjacent vertices %d-%d (an odometry edge, "
+                        "reference src/utils.cpp:184)", k, f, t);
+    }
     HIPCHK(hipSetDevice(h->device));
     if (int rc = spec_quiesce(h, true)) return rc;
     free_candidates(h);
     h->last_cells = 0;
     h->ev_valid = false;
-    h->cns.clear();
+    if (!preserve_state) {
+        h->cns.clear();
+        if (h->d_cur && h->d_open)
+            HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
+    }
     h->h_from.clear(); h->h_to.clear();
-    if (h->d_cur && h->d_open)
-        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
+    {   // host copy of the raw records (ipc_append_candidate re-uploads the grown list)
+        const int ms_ = h->dim == 2 ? 3 : 7, is_ = h->dim == 2 ? 6 : 21;
+        std::vector<int> ci(ids, ids + 2 * (size_t)n);
+        std::vector<double> cm(meas, meas + (size_t)ms_ * n), cinf(info, info + (size_t)is_ * n);
+        h->h_cand_ids.swap(ci); h->h_cand_meas.swap(cm); h->h_cand_info.swap(cinf);
+    }
     if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
     std::vector<int> from(n), to(n);
     h->h_lo.resize(n); h->h_hi.resize(n);
     for (int k = 0; k < n; ++k) {
         from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
-        if (from[k] < 0 || to[k] < 0 || from[k] >= h->V || to[k] >= h->V)
-            return fail(IPC_ERR_ARG, "candidate %d joins vertex %d-%d outside 0..%d", k, from[k], to[k], h->V - 1);
-        if (std::abs(from[k] - to[k]) < 2)
-            return fail(IPC_ERR_ARG, "candidate %d joins adjacent vertices %d-%d (an odometry edge, "
-                        "reference src/utils.cpp:184)", k, from[k], to[k]);
         h->h_lo[k] = std::min(from[k], to[k]); h->h_hi[k] = std::max(from[k], to[k]);
     }
     // cmpTime order (src/utils.cpp:379-390) with the (max id, index) tie-break
@@ -816,6 +828,28 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
     HIPCHK(hipStreamSynchronize(h->own_stream));
     HIPCHK(hipFree(d_m));
     HIPCHK(hipFree(d_i));
+    return IPC_OK;
+}
+
+extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* meas, const double* info)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_set_candidates: NULL handle");
+    if (n < 0 || (n > 0 && (!ids || !meas || !info))) return fail(IPC_ERR_ARG, "ipc_set_candidates: bad arrays");
+    return upload_candidates(h, n, ids, meas, info, false);
+}
+
+extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const double* meas, const double* info, int* index_out)
+{
+    if (!h || !ids || !meas || !info) return fail(IPC_ERR_ARG, "ipc_append_candidate: NULL argument");
+    const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
+    std::vector<int> ci = h->h_cand_ids;
+    std::vector<double> cm = h->h_cand_meas, cinf = h->h_cand_info;
+    const int n = (int)ci.size() / 2;
+    ci.insert(ci.end(), ids, ids + 2);
+    cm.insert(cm.end(), meas, meas + ms);
+    cinf.insert(cinf.end(), info, info + is);
+    if (int rc = upload_candidates(h, n + 1, ci.data(), cm.data(), cinf.data(), true)) return rc;
+    if (index_out) *index_out = n;
     return IPC_OK;
 }
 

@@ -8,10 +8,27 @@
 #include <vector>
 
 namespace g2o {
-struct Vertex { int _id = 0; int id() const { return _id; } };
-template <int D> struct Mat { double v[D][D] = {}; double operator()(int i, int j) const { return v[i][j]; } };
-struct SE2 { std::array<double, 3> m{}; std::array<double, 3> toVector() const { return m; } };
-struct Isometry3 { std::array<double, 7> qt{}; };                 // x y z qx qy qz qw
+struct Vertex {
+    int _id = 0; bool _fixed = false;
+    int id() const { return _id; }
+    void setFixed(bool f) { _fixed = f; }
+};
+template <int D> struct Mat {
+    double v[D][D] = {};
+    double operator()(int i, int j) const { return v[i][j]; }
+    Mat operator*(double s) const { Mat r; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) r.v[i][j] = v[i][j] * s; return r; }
+    Mat operator/(double s) const { Mat r; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) r.v[i][j] = v[i][j] / s; return r; }
+};
+// (poses only need to compose somehow for propagateGuess to compile and leave a trace: the mock adds component-wise)
+struct SE2 {
+    std::array<double, 3> m{};
+    std::array<double, 3> toVector() const { return m; }
+    SE2 operator*(const SE2& o) const { SE2 r; for (int k = 0; k < 3; ++k) r.m[k] = m[k] + o.m[k]; return r; }
+};
+struct Isometry3 {
+    std::array<double, 7> qt{};                                    // x y z qx qy qz qw
+    Isometry3 operator*(const Isometry3& o) const { Isometry3 r; for (int k = 0; k < 7; ++k) r.qt[k] = qt[k] + o.qt[k]; return r; }
+};
 namespace internal { inline std::array<double, 7> toVectorQT(const Isometry3& t) { return t.qt; } }
 struct OptimizableGraph {
     struct Edge {
@@ -24,15 +41,23 @@ template <int D, class MEAS> struct Edge : OptimizableGraph::Edge {
     MEAS _m; Mat<D> _info;
     const MEAS& measurement() const { return _m; }
     const Mat<D>& information() const { return _info; }
+    void setInformation(const Mat<D>& i) { _info = i; }
 };
 using EdgeSE2 = Edge<3, SE2>;
 using EdgeSE3 = Edge<6, Isometry3>;
-struct VertexSE2 : Vertex {};
-struct VertexSE3 : Vertex {};
+template <class POSE> struct PoseVertex : Vertex {
+    POSE _est;
+    const POSE& estimate() const { return _est; }
+    void setEstimate(const POSE& p) { _est = p; }
+    void setToOrigin() { _est = POSE(); }
+};
+using VertexSE2 = PoseVertex<SE2>;
+using VertexSE3 = PoseVertex<Isometry3>;
 struct SparseOptimizer {
     std::map<int, Vertex*> _vertices;
     std::vector<void*> _edges;
     const std::map<int, Vertex*>& vertices() const { return _vertices; }
+    Vertex* vertex(int id) { return _vertices.at(id); }
     void clear() { _vertices.clear(); _edges.clear(); }
 };
 }  // namespace g2o

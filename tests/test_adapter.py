@@ -13,6 +13,7 @@ MOCK = os.path.join(ROOT, "tests", "mock_ref")
 
 
 def _compile(out, link):
+    # this repo's include/ in FRONT of the (mock of the) reference's: "ipc/consensus.hpp" resolves to the shim
     cmd = ["g++", "-O1", "-std=c++14", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + MOCK,
            os.path.join(MOCK, "adapter_main.cpp")]
     if link:
@@ -45,10 +46,18 @@ def test_adapter_replays_the_harness_loop(tmp_path, dim, spoiled):
     eng = IPC(g, Config(prm[1], prm[2], prm[3], prm[4], prm[0]))
     eng.reset()
     want = [int(eng.agreementCheck(int(k))) for k in eng.candidate_order()]
+    # the harness's own path: candidates handed to agreementCheck one by one, never announced (src/simulation.cpp:34-47)
     assert [int(x) for x in lines["decisions"].split()] == want
     assert int(lines["set"]) == sum(want)
+    # ... and with the list announced first
+    assert [int(x) for x in lines["announced"].split()] == want
+    # the constructor scaled the caller's odometry information in place (robustifyVoters, src/consensus.cpp:21) and the
+    # harness's own division (src/simulation.cpp:56) brings back what the file holds, before its final optimize(1000)
+    assert float(lines["ctor_info_scale"]) <= 1e-15
+    assert float(lines["harness_info_restore"]) <= 4e-16
+    assert lines["harness_vertices_propagated"] == "1"
     if sum(want):
-        assert lines["removed"] == "1 -> %d" % (sum(want) - 1)
+        assert lines["removed"] == "1 -> %d" % (sum(want) - 1)     # by an edge OBJECT the engine never saw: ids decide
         assert lines["added"] == "-> %d" % sum(want)
     _, acc = eng.run()
     assert int(lines["matrix"].split()[1]) == int(acc.sum())

@@ -283,8 +283,11 @@ def test_matrix_mode_vs_faithful_incremental_mode(oracle):
     assert acc[20:].sum() == 0 and inc[20:].sum() == 0
     agree = float((acc == inc).mean())
     assert agree >= 0.9, agree
-    # the matrix mode is the stricter one on true loops (the diagonal uses the fast threshold)
-    assert np.all(acc <= inc) or agree >= 0.95
+    # Neither formulation is the stricter one in general: the matrix mode tests a candidate against each accepted edge
+    # in a TWO-loop problem, the reference against all overlapping accepted edges jointly, from the poses they left.  On
+    # the bench workloads the matrix mode is the more permissive (tests/test_gpu_persistent.py::
+    # test_candidates_on_which_matrix_mode_and_the_reference_algorithm_differ lists the candidates).
+    assert agree >= 0.95 or np.all(acc <= inc) or np.all(inc <= acc)
 
 
 def test_kernel_families_agree_with_each_other(oracle, monkeypatch):
