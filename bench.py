@@ -30,16 +30,7 @@ import torch
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64: vector == dense MFMA rate (half the 157.3 TF FP32 rate)
 HBM_PEAK_GBS = 8000.0
 
-# per-pose operation counts of the SE2 kernel (DESIGN.md "Kernel op count")
-F_ITER = {1: 272.0, 2: 447.0}    # b, alpha, capacitance reduction, step, scans -- per outer iteration
-F_EVAL = 80.0                    # sincos + residual + chi2 -- per error evaluation
-F_TRY = 70.0                     # step candidate, linear gain, update -- per evaluated trial
 B_ODOM = 72.0                    # bytes of one odometry record (3 + 6 doubles), SURVEY.md 8d
-# SE3 (6x6 blocks): SURVEY.md 8(d)'s figure F_6 = 3000 flops per pose and outer iteration, trial evaluations
-# included (the executed count from the SQ_INSTS_VALU_*_F64 counters is reported next to it)
-F_ITER3 = {1: 3000.0, 2: 3000.0}
-F_EVAL3 = 0.0
-F_TRY3 = 0.0
 B_ODOM3 = 224.0                  # 7 + 21 doubles
 F_SURVEY = {2: 450.0, 3: 3000.0}  # SURVEY.md 8(d) placeholders: flops per pose and outer iteration
 
@@ -148,9 +139,9 @@ def cpu_baseline(g, cfg, cells, budget_s):
     mx = mxa if n_all >= n1 else mx1
     mism = int(((~(mx > th[idx])) != (~(cells["max_chi2"][idx] > th[idx]))).sum())
     rel = np.abs(mx - cells["max_chi2"][idx]) / np.maximum(np.abs(mx), 1e-300)
-    one = dict(value=n1 / t1, unit="candidate-pairs/s", cores=1, kind="port",
+    one = dict(value=n1 / t1, unit="solved candidate-pairs/s", cores=1, kind="port",
                sample="%d solved cells (prefix of the all-core sample), %.1f s, one run" % (n1, t1))
-    return dict(value=n_all / t_all, unit="candidate-pairs/s", cores=used, kind="port",
+    return dict(value=n_all / t_all, unit="solved candidate-pairs/s (compare with solved_cells_per_s, not with value)", cores=used, kind="port",
                 sample="%d solved cells, L-stratified over the chain-length order of the same workload, static "
                        "partition over %d POSIX threads (host reports %d cores), median of 5 runs (%.2f s each); "
                        "the CPU side is this repo's plain-C restatement (oracle/), not g2o -- the reference cannot be "
@@ -210,23 +201,42 @@ def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload):
     return out
 
 
+def kernel_source_digest():
+    """sha256 over the cell-solver kernel sources: a committed counter pass belongs to the build it was taken on."""
+    import hashlib
+    hh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ipc_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.startswith(("se2_", "se3_", "block_prims", "cell_kernels")):
+            hh.update(open(os.path.join(csrc, f), "rb").read())
+    return hh.hexdigest()[:16]
+
+
 def executed_flops(workload, dim):
-    """Executed FP64 flops of the cell-solver kernels of ONE solve of this workload, from the committed rocprofv3
-    PMC pass profiles/r2_<workload>_pmc_sq.csv (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 are wave-level
-    instruction counts: x 64 lanes, FMA = 2 flops).  None when no such file is committed."""
-    path = os.path.join(ROOT, "profiles", "r2_%s_pmc_sq.csv" % workload.lower())
-    if not os.path.exists(path):
-        return None
+    """Executed FP64 flops of the cell-solver kernels of ONE solve of this workload, from the committed rocprofv3 PMC
+    pass profiles/r<round>_<workload>_pmc_sq.csv (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 are wave-level instruction
+    counts: x 64 lanes, FMA = 2 flops).  `current` says whether the pass was taken on the kernel sources of this build
+    (sidecar .meta.json written by tools/profile_pmc.sh; passes without one predate the check).  None: no such file."""
     import csv
+    for rnd in ("r3", "r2"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.csv" % (rnd, workload.lower()))
+        if os.path.exists(path):
+            break
+    else:
+        return None
     c = {}
     for r in csv.DictReader(open(path)):
         if any(t in r["kernel"] for t in ("_cells_kernel", "_wave_kernel", "_group_kernel", "_lds_kernel")):
             c[r["counter"]] = c.get(r["counter"], 0.0) + float(r["sum_value"])
     if "SQ_INSTS_VALU_FMA_F64" not in c:
         return None
+    meta = os.path.splitext(path)[0] + ".meta.json"
+    current = None
+    if os.path.exists(meta):
+        current = json.load(open(meta)).get("kernel_source_digest") == kernel_source_digest()
     return dict(flops=64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0.0)
                               + c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)),
-                mfma_mops_f64=c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), source=os.path.relpath(path, ROOT))
+                mfma_mops_f64=c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), source=os.path.relpath(path, ROOT), current=current)
 
 
 def main():
@@ -297,10 +307,7 @@ def main():
     cells = eng.cell_info()                            # this rank's solved cells
     L = (cells["hi"] - cells["lo"]).astype(np.float64)
     nl = np.where(cells["i"] == cells["j"], 1, 2)
-    fi, fe, ft, bo = (F_ITER, F_EVAL, F_TRY, B_ODOM) if g.dim == 2 else (F_ITER3, F_EVAL3, F_TRY3, B_ODOM3)
-    f_iter = np.where(nl == 1, fi[1], fi[2])
-    flops = float((L * (cells["iterations"] * f_iter + cells["evals"] * fe
-                        + np.maximum(cells["evals"] - 1, 0) * ft)).sum())
+    bo = B_ODOM if g.dim == 2 else B_ODOM3
     alg_bytes = float((L * bo + nl * bo + 1.0 / 8).sum())
     # HBM traffic of the solver kernels from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE / WRITE_SIZE in KB, separate passes; FETCH_SIZE doubled per the gfx950 note in
@@ -317,16 +324,25 @@ def main():
                 elif r["counter"] == "WRITE_SIZE":
                     w += float(r["sum_value"])
         traffic = (2.0 * f + w) * 1024.0
-    achieved_tflops = flops / (sms * 1e-3) / 1e12
     pose_iters = float((L * cells["iterations"]).sum())
+    survey_flops = pose_iters * F_SURVEY[g.dim]                 # 450 / 3000 flop per pose and outer iteration
     ex = executed_flops(args.workload, g.dim) if world == 1 else None
-    roofline = {"bound": "mfma", "compute_unit": "fp64-valu", "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
+    # `achieved` / `frac`: EXECUTED FP64 flops of one step (counter pass of this workload, committed under profiles/) over
+    # this run's HIP-event kernel time, when such a pass exists for the kernels of this build; otherwise SURVEY's model.
+    use_ex = ex is not None and ex["current"] is not False
+    ach_flops = ex["flops"] if use_ex else survey_flops
+    achieved_tflops = ach_flops / (sms * 1e-3) / 1e12
+    roofline = {"bound": "fp64-valu", "contract_bound": "mfma",
+                "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
-                "frac_survey_model": round(pose_iters * F_SURVEY[g.dim] / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
-                "executed_fp64_flops_per_step": ex["flops"] if ex else None,
+                "frac_basis": ("executed FP64 flops (%s: SQ_INSTS_VALU_{FMA x2,MUL,ADD,TRANS}_F64 x 64 lanes of one solve of "
+                               "this workload = %.4g) / kernel_ms_per_step / peak" % (ex["source"], ex["flops"])) if use_ex
+                              else "SURVEY.md 8(d) model: pose_iterations_per_step x %g flop / kernel_ms_per_step / peak" % F_SURVEY[g.dim],
+                "frac_survey_model": round(survey_flops / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
                 "frac_executed": round(ex["flops"] / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if ex else None,
-                "executed_source": (ex["source"] + " (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 of one solve of this workload; "
-                                    "SQ_INSTS_VALU_MFMA_MOPS_F64 = %s)" % ex["mfma_mops_f64"]) if ex else None,
+                "executed_fp64_flops_per_step": ex["flops"] if ex else None,
+                "executed_pass_is_of_this_build": ex["current"] if ex else None,
+                "mfma_mops_f64": ex["mfma_mops_f64"] if ex else None,
                 "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
                                 "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
                                 "L2-resident" % args.workload,
@@ -334,11 +350,10 @@ def main():
                     "se2_wave_kernel<M,NL,STAGED> + se2_group_kernel<W,M,NL,STAGED> + se2_cells_kernel<W,M,NL>" if g.dim == 2
                     else "se3_lds_kernel<W,M,NL> (+ se3_cells_kernel<W,M,NL> beyond 2560 poses)", launches),
                 "kernel_ms_per_step": round(sms, 4),
-                "algorithmic_flops_per_step": flops,
                 "pose_iterations_per_step": pose_iters,
-                "note": "compute-bound: priced against the dense FP64 MFMA peak, which on MI355X equals the FP64 "
-                        "vector-ALU peak (78.6 TFLOP/s); the work has no MFMA-shaped products, its instructions "
-                        "issue on the FP64 VALU; the HBM roof is far away, see roofline_hbm"}
+                "note": "compute-bound on the FP64 vector ALU (no MFMA-shaped products: SQ_INSTS_VALU_MFMA_MOPS_F64 = 0); "
+                        "the contract's enum has no VALU entry, its 'mfma' roof for f64 is the same 78.6 TFLOP/s; the HBM "
+                        "roof is far away, see roofline_hbm"}
     hbm_gbs = alg_bytes / (sms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(hbm_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -367,7 +382,11 @@ def main():
     bits, acc = sm.result()
     out["accepted"] = int(acc.sum())
     out["solved_cells_rank0"] = int(len(cells))
-    out["solved_cells_per_s"] = len(cells) * world * 1.0 / (ms_per_step * 1e-3) if world == 1 else None
+    # cells whose intervals do not overlap cost nothing (C[i][j] = C[i][i] & C[j][j]): `value` counts them, as the metric
+    # is defined over all N(N+1)/2 pairs; the rate over the cells that are actually solved is the one to compare with
+    # cpu_baseline (which times solved cells only)
+    out["solved_cells_per_s"] = len(cells) * 1.0 / (ms_per_step * 1e-3) if world == 1 else None
+    out["free_cells_in_value"] = int(n_cells_total - len(cells)) if world == 1 else None
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, cfg, cells, args.cpu_seconds)
         gpu_solved_rate = len(cells) * 1.0 / (ms_per_step * 1e-3)

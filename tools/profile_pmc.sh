@@ -15,6 +15,8 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INS
 cd $root
 python tools/rocpd_summary.py $(find $out/trace -name "*.db" | head -1) > $out/kernel_stats.csv
 python tools/rocpd_pmc.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) > $out/pmc_sq.csv
+# which build the counters belong to (bench.py marks a pass of other kernel sources as stale)
+python -c "import json, bench; print(json.dumps(dict(kernel_source_digest=bench.kernel_source_digest(), workload='$wl', policy_env=dict(IPC_SE2_POLICY='${IPC_SE2_POLICY:-}', IPC_SE3_POLICY='${IPC_SE3_POLICY:-}', IPC_TERMINATE_EPS='${IPC_TERMINATE_EPS:-}'))))" > $out/pmc_sq.meta.json
 find $out -name "*.db" -delete
 find $out -name "*.csv" -size +2M -delete
 head -12 $out/kernel_stats.csv
