@@ -119,12 +119,16 @@ int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void
 typedef struct {
     int cells;               /* solved cells                                                   */
     int long_cells;          /* of those, solved by the cluster-solver fallback                */
-    int failed_cells;        /* linear solve hit a non-positive pivot (flags & 2): the cell's
-                                chi2 is that of the last good state, g2o would have retried with
-                                Levenberg damping -- treat a non-zero count as a warning       */
+    int failed_cells;        /* the optimisation ended in g2o's Fail state (flags & 2): the linear solve kept meeting
+                                non-positive pivots up to the largest Levenberg damping (or the sub-problem is too
+                                large for the damped solver, > 24 000 unknowns); the cell's chi2 is that of the last
+                                good state                                                                          */
     int capped_cells;        /* ran to the iteration cap without the dog-leg terminating       */
     int nan_cells;           /* max chi2 is NaN (counts as "agrees", like chi2 > th does in
                                 the reference, src/consensus_utils.cpp:18)                     */
+    int damped_cells;        /* cells whose linear solve met a non-positive pivot and were solved again with g2o's
+                                Levenberg retry (lambda 1e-7 x 10 per failure up to 1e3, sticky for the rest of the
+                                optimisation) on the literal normal equations                                      */
 } ipc_solve_report_t;
 int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out);
 

@@ -138,24 +138,48 @@ struct LoopTables {
 
 // Ops:  evaluate_committed(chi) | linearize(bb, bHb, hh, bh, info) | blend(alpha, c, bma)
 //       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
+//       | damped_solve(lambda, ok, hh, bh, bHh, hHh)   (H + lambda I) h = b on the literal normal equations
+//
+// Levenberg retry of the linear solve (g2o OptimizationAlgorithmDogleg::solve, restated in oracle/ipc_oracle.c
+// sub_optimize): the Gauss-Newton step is first asked of the plain system; once a factorisation has met a
+// non-positive pivot (`wasPD` false, sticky for the rest of the optimisation) every solve adds currentLambda to the
+// diagonal of H -- times 10 per failure up to 1e3, then Fail; divided by 5 (not below 1e-12) per success.  The
+// capacitance formulation of the cluster solvers cannot carry lambda (H + lambda I is not chain-structured in the
+// u = J_c h variables), so damped solves go to Ops::damped_solve: the dense normal equations of g2o's own H.
 template <class Ops>
-hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term_eps = 0.0, int n_edges = 1)
+hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term_eps = 0.0, int n_edges = 1, bool allow_damping = true)
 {
     out = ClusterOut{};
     double currentChi;
     IPC_CL_CHK(ops.evaluate_committed(currentChi));
     out.chi2_initial = currentChi;
-    double delta = 1e4;
+    double delta = 1e4, currentLambda = 1e-7;
+    const double lambdaFactor = 10.0, minLambda = 1e-12, maxLambda = 1e3;
     const int maxTrials = 100;
-    bool lastGN = false;
+    bool lastGN = false, wasPD = true;
     for (int it = 0; it < iterations; ++it) {
         double bb, bHb, hh, bh;
         int info = 0;
         IPC_CL_CHK(ops.linearize(bb, bHb, hh, bh, info));
-        if (info != 0) { out.flags |= 2; out.iterations = it + 1; break; }
-        const double hHh = bh;                        // H h_gn = b
+        double hHh = bh, bHh = bb;                    // H h_gn = b (plain solve)
+        {
+            bool solverOk = wasPD && info == 0, failed = false, first = true;
+            while (!solverOk) {
+                if (!first || wasPD) {                // a solve has just failed: g2o's bookkeeping
+                    wasPD = false;
+                    currentLambda *= lambdaFactor;
+                    if (currentLambda > maxLambda) { currentLambda = maxLambda; failed = true; break; }
+                }
+                first = false;
+                if (!allow_damping) { failed = true; break; }
+                bool ok = false;
+                IPC_CL_CHK(ops.damped_solve(currentLambda, ok, hh, bh, bHh, hHh));
+                if (ok) { solverOk = true; currentLambda = std::max(currentLambda / (0.5 * lambdaFactor), minLambda); }
+            }
+            if (failed) { out.flags |= 2; out.iterations = it + 1; break; }
+        }
         const double alpha = bb / bHb, hsdNorm = std::sqrt(alpha * alpha * bb), hgnNorm = std::sqrt(hh);
-        if (lastGN && hgnNorm < delta && std::fabs(bh) * n_edges < term_eps * currentChi) {   // converged (Se2View::term_eps)
+        if (wasPD && lastGN && hgnNorm < delta && std::fabs(bh) * n_edges < term_eps * currentChi) {   // converged (Se2View::term_eps)
             out.iterations = it + 1; out.tries += maxTrials; out.flags |= 1;
             break;
         }
@@ -180,7 +204,7 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term
             if (stepType == 0) { pcoef = 0.0; qcoef = 1.0; hdlNorm = hgnNorm; }
             else if (stepType == 1) { pcoef = sdScale * alpha; qcoef = 0.0; hdlNorm = delta; }
             else { pcoef = alpha - beta * alpha; qcoef = beta; hdlNorm = delta; }
-            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bb + qcoef * qcoef * hHh;
+            const double hdlHhdl = pcoef * pcoef * bHb + 2 * pcoef * qcoef * bHh + qcoef * qcoef * hHh;
             const double bhdl = pcoef * bb + qcoef * bh;
             double linearGain = -1 * hdlHhdl + 2 * bhdl;
             double newChi;
@@ -214,6 +238,7 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term
     }
     IPC_CL_CHK(ops.max_edge_chi2(out.max_chi2));
     out.chi2_total = currentChi;
+    if (!wasPD) out.flags |= 4;                       // the linear solve needed Levenberg damping
     return hipSuccess;
 }
 

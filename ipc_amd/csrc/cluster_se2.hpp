@@ -398,6 +398,134 @@ __global__ void gk_update(ClusterDev D, double p, double q)
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
+// ---- literal normal equations (Levenberg retry, cluster_common.hpp::cluster_dogleg) ---------------------------
+// g2o's own system for the sub-graph: H = sum_e J_e^T Om_e J_e over the chain edges 1..L and the loops, poses 1..L
+// free (pose 0 is the gauge), + lambda on the diagonal; Hd is the (n+1) x n column-major array dense_chol.hpp factors
+// (n = 3 L, lower triangle, right-hand side b in row n).  One thread per pose builds its diagonal block and the
+// off-diagonal blocks it is the LATER end of, in a fixed order (no atomics: same bits every run).
+__device__ __forceinline__ void gk_edge_J(const Pose2& a, const Pose2& b, double cz, double sz, double (&Ja)[3][3], double (&Jb)[3][3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double u0 = k == 0 ? 1.0 : 0.0, u1 = k == 1 ? 1.0 : 0.0, u2 = k == 2 ? 1.0 : 0.0;
+        se2_apply_J(a, b, cz, sz, u0, u1, u2, 0.0, 0.0, 0.0, Ja[0][k], Ja[1][k], Ja[2][k]);
+        se2_apply_J(a, b, cz, sz, 0.0, 0.0, 0.0, u0, u1, u2, Jb[0][k], Jb[1][k], Jb[2][k]);
+    }
+}
+// out += A^T Om B
+__device__ __forceinline__ void gk_atob(const double (&A)[3][3], const Sym3& om, const double (&B)[3][3], double (&out)[3][3])
+{
+    double OB[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) om.mul(B[0][c], B[1][c], B[2][c], OB[0][c], OB[1][c], OB[2][c]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[r][c] += A[0][r] * OB[0][c] + A[1][r] * OB[1][c] + A[2][r] * OB[2][c];
+}
+__global__ void gk_dense_H(ClusterDev D, double* Hd, double lambda)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < 1 || p > D.L) return;
+    const int n = 3 * D.L, ldh = n + 1;
+    double dg[3][3] = {{lambda, 0, 0}, {0, lambda, 0}, {0, 0, lambda}};
+    auto put = [&](int prow, int pcol, const double (&B)[3][3], bool add) {      // block (prow, pcol), prow > pcol >= 1
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double* q = &Hd[(size_t)(3 * (pcol - 1) + c) * ldh + 3 * (prow - 1) + r];
+                *q = add ? *q + B[r][c] : B[r][c];
+            }
+    };
+    {   // chain edge p (poses p-1 -> p): this pose is its second end
+        const int k = D.lo + p - 1;
+        double Ja[3][3], Jb[3][3];
+        gk_edge_J(gk_pose(D.X, p - 1), gk_pose(D.X, p), D.chain[(size_t)F_CZ * D.estride + k], D.chain[(size_t)F_SZ * D.estride + k], Ja, Jb);
+        const Sym3 om = gk_sym(D.chain, D.estride, F_OM, k);
+        gk_atob(Jb, om, Jb, dg);
+        if (p >= 2) { double off[3][3] = {}; gk_atob(Jb, om, Ja, off); put(p, p - 1, off, false); }
+    }
+    if (p < D.L) {   // chain edge p+1 (poses p -> p+1): first end
+        const int k = D.lo + p;
+        double Ja[3][3], Jb[3][3];
+        gk_edge_J(gk_pose(D.X, p), gk_pose(D.X, p + 1), D.chain[(size_t)F_CZ * D.estride + k], D.chain[(size_t)F_SZ * D.estride + k], Ja, Jb);
+        gk_atob(Ja, gk_sym(D.chain, D.estride, F_OM, k), Ja, dg);
+    }
+    for (int q = D.adj_ptr[p]; q < D.adj_ptr[p + 1]; ++q) {
+        const int it = D.adj_item[q], l = it >> 1, c = D.lcand[l];
+        const int f = D.lfrom[l], t = D.lto[l];
+        double Ja[3][3], Jb[3][3];
+        gk_edge_J(gk_pose(D.X, f), gk_pose(D.X, t), D.cand[(size_t)F_CZ * D.cstride + c], D.cand[(size_t)F_SZ * D.cstride + c], Ja, Jb);
+        const Sym3 om = gk_sym(D.cand, D.cstride, F_OM, c);
+        if (it & 1) gk_atob(Jb, om, Jb, dg); else gk_atob(Ja, om, Ja, dg);
+        const int other = (it & 1) ? f : t;
+        if (other >= 1 && other < p) {                // this pose is the later end: the off-diagonal block is its job
+            double off[3][3] = {};
+            if (it & 1) gk_atob(Jb, om, Ja, off); else gk_atob(Ja, om, Jb, off);
+            put(p, other, off, true);                  // (several loops may join the same pair: accumulated in list order)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) Hd[(size_t)(3 * (p - 1) + c) * ldh + 3 * (p - 1) + r] = dg[r][c];
+        Hd[(size_t)(3 * (p - 1) + r) * ldh + n] = D.b[r * D.ld + p];
+    }
+}
+// h <- the dense solution; partial |h|^2, b.h
+__global__ void gk_h_from_dense(ClusterDev D, const double* x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    if (i >= 1 && i <= D.L) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double hk = x[3 * (i - 1) + k];
+            D.h[k * D.ld + i] = hk;
+            v[0] += hk * hk;
+            v[1] += D.b[k * D.ld + i] * hk;
+        }
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+// partial b^T H h and h^T H h over the edges (H without lambda)
+__global__ void gk_quad_bh(ClusterDev D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    auto vec = [&](const double* a, int p, double& x0, double& x1, double& x2) {
+        x0 = p > 0 ? a[p] : 0.0; x1 = p > 0 ? a[D.ld + p] : 0.0; x2 = p > 0 ? a[2 * D.ld + p] : 0.0;
+    };
+    int f = -1, t = -1;
+    double cz = 0, sz = 0;
+    Sym3 om{};
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        f = i - 1; t = i;
+        cz = D.chain[(size_t)F_CZ * D.estride + k]; sz = D.chain[(size_t)F_SZ * D.estride + k];
+        om = gk_sym(D.chain, D.estride, F_OM, k);
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1, c = D.lcand[l];
+        f = D.lfrom[l]; t = D.lto[l];
+        cz = D.cand[(size_t)F_CZ * D.cstride + c]; sz = D.cand[(size_t)F_SZ * D.cstride + c];
+        om = gk_sym(D.cand, D.cstride, F_OM, c);
+    }
+    if (f >= 0) {
+        const Pose2 a = gk_pose(D.X, f), b = gk_pose(D.X, t);
+        double a0, a1, a2, b0, b1, b2, wb0, wb1, wb2, wh0, wh1, wh2;
+        vec(D.b, f, a0, a1, a2); vec(D.b, t, b0, b1, b2);
+        se2_apply_J(a, b, cz, sz, a0, a1, a2, b0, b1, b2, wb0, wb1, wb2);
+        vec(D.h, f, a0, a1, a2); vec(D.h, t, b0, b1, b2);
+        se2_apply_J(a, b, cz, sz, a0, a1, a2, b0, b1, b2, wh0, wh1, wh2);
+        double o0, o1, o2;
+        om.mul(wh0, wh1, wh2, o0, o1, o2);
+        v[0] = wb0 * o0 + wb1 * o1 + wb2 * o2;
+        v[1] = wh0 * o0 + wh1 * o1 + wh2 * o2;
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
@@ -422,8 +550,12 @@ public:
     hipError_t trial(double p, double q, double& newChi, bool& anyChanged);
     void commit() { std::swap(dev_.X, dev_.Xn); std::swap(dev_.e, dev_.en); std::swap(dev_.le, dev_.len); }
     hipError_t max_edge_chi2(double& mx);
+    hipError_t damped_solve(double lambda, bool& ok, double& hh, double& bh, double& bHh, double& hHh);
+    bool allow_damping = true;          // Levenberg retry of a failed linear solve (dense normal equations, <= kMaxDenseN unknowns)
+    static constexpr int kMaxDenseN = 24000;
 
 private:
+    double* d_H_ = nullptr; size_t capH_ = 0;       // dense system + factor of damped_solve
     ClusterDev dev_{};
     hipStream_t st_ = nullptr;
     int nblk_ = 1;
@@ -437,7 +569,7 @@ private:
     void release()
     {
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_scal_);
-        hipFree(d_int_);
+        hipFree(d_int_); hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
         if (h_scal_) hipHostFree(h_scal_);
         d_edge_ = d_loop_ = d_S_ = d_partial_ = d_scal_ = nullptr; d_int_ = d_info_ = nullptr; h_scal_ = nullptr;
         capL_ = capNl_ = 0;
@@ -515,6 +647,36 @@ inline hipError_t ClusterSolver2::linearize(double& bb, double& bHb, double& hh,
     return hipSuccess;
 }
 
+inline hipError_t ClusterSolver2::damped_solve(double lambda, bool& ok, double& hh, double& bh, double& bHh, double& hHh)
+{
+    ClusterDev& D = dev_;
+    const int n = 3 * D.L;
+    ok = false;
+    if (n > kMaxDenseN) return hipSuccess;                       // (too large for the dense fallback: the solve reports Fail)
+    const size_t m = (size_t)(n + 1) * n;
+    if (2 * m > capH_) {
+        hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
+        IPC_CL_CHK(hipMalloc(&d_H_, sizeof(double) * 2 * m));
+        capH_ = 2 * m;
+    }
+    IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
+    IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
+    hipLaunchKernelGGL(gk_dense_H, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, d_H_, lambda);
+    IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));      // (solution in the scan workspace: 3 ld doubles)
+    hipLaunchKernelGGL(gk_h_from_dense, dim3(nblk_), dim3(kGB), 0, st_, D, (const double*)D.sc);
+    sum_partials(2, 2);
+    hipLaunchKernelGGL(gk_quad_bh, dim3(nblk_), dim3(kGB), 0, st_, D);
+    sum_partials(2, 4);
+    IPC_CL_CHK(hipGetLastError());
+    IPC_CL_CHK(fetch(6));
+    int info;
+    std::memcpy(&info, h_scal_ + 12, sizeof(int));
+    hh = h_scal_[2]; bh = h_scal_[3]; bHh = h_scal_[4]; hHh = h_scal_[5];
+    ok = info == 0 && hh == hh;
+    IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
+    return hipSuccess;
+}
+
 inline hipError_t ClusterSolver2::blend(double alpha, double& c, double& bma)
 {
     hipLaunchKernelGGL(gk_blend, dim3(nblk_), dim3(kGB), 0, st_, dev_, alpha);
@@ -589,7 +751,7 @@ inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int
         IPC_CL_CHK(hipMemcpyAsync(xp[k], sp[k] + lo, sizeof(double) * (L + 1), hipMemcpyDeviceToDevice, st));
     nblk_ = (L + nl + 1 + kGB - 1) / kGB;            // indices 0 .. L+nl
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
-    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl);
+    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl, allow_damping);
 }
 
 }  // namespace ipc

@@ -521,6 +521,161 @@ __global__ void gk3_update(ClusterDev3 D, double p, double q)
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
+// ---- literal normal equations (Levenberg retry, cluster_common.hpp::cluster_dogleg): SE(3) counterpart of
+// cluster_se2.hpp's gk_dense_H / gk_h_from_dense / gk_quad_bh (6 x 6 blocks, n = 6 L unknowns) ------------------
+__device__ __forceinline__ void gk3_edge_J(const Edge3& E, double (&Ja)[6][6], double (&Jb)[6][6])
+{
+    const double z[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double u[6] = {0, 0, 0, 0, 0, 0}, w[6];
+        u[k] = 1.0;
+        se3_apply_J(E, u, z, w);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Ja[r][k] = w[r];
+        se3_apply_J(E, z, u, w);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Jb[r][k] = w[r];
+    }
+}
+// out += A^T Om B
+__device__ __forceinline__ void gk3_atob(const double (&A)[6][6], const double* om, const double (&B)[6][6], double (&out)[6][6])
+{
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double col[6], oc[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = B[r][c];
+        sym6_mul(om, col, oc);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc += A[q][r] * oc[q];
+            out[r][c] += acc;
+        }
+    }
+}
+__global__ void gk3_dense_H(ClusterDev3 D, double* Hd, double lambda)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < 1 || p > D.L) return;
+    const int n = 6 * D.L, ldh = n + 1;
+    double dg[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dg[r][c] = r == c ? lambda : 0.0;
+    auto put = [&](int prow, int pcol, const double (&B)[6][6], bool add) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double* q = &Hd[(size_t)(6 * (pcol - 1) + c) * ldh + 6 * (prow - 1) + r];
+                *q = add ? *q + B[r][c] : B[r][c];
+            }
+    };
+    double Rz[9], tz[3], om[21];
+    {
+        const int k = D.lo + p - 1;
+        gk3_rz(D.chain, D.estride, k, Rz, tz);
+        Edge3 E;
+        se3_edge(gk3_pose(D.X, D.ld, p - 1), gk3_pose(D.X, D.ld, p), Rz, tz, E);
+        double Ja[6][6], Jb[6][6];
+        gk3_edge_J(E, Ja, Jb);
+        gk3_sym(D.chain, D.estride, G_OM, k, om);
+        gk3_atob(Jb, om, Jb, dg);
+        if (p >= 2) {
+            double off[6][6] = {};
+            gk3_atob(Jb, om, Ja, off);
+            put(p, p - 1, off, false);
+        }
+    }
+    if (p < D.L) {
+        const int k = D.lo + p;
+        gk3_rz(D.chain, D.estride, k, Rz, tz);
+        Edge3 E;
+        se3_edge(gk3_pose(D.X, D.ld, p), gk3_pose(D.X, D.ld, p + 1), Rz, tz, E);
+        double Ja[6][6], Jb[6][6];
+        gk3_edge_J(E, Ja, Jb);
+        gk3_sym(D.chain, D.estride, G_OM, k, om);
+        gk3_atob(Ja, om, Ja, dg);
+    }
+    for (int q = D.adj_ptr[p]; q < D.adj_ptr[p + 1]; ++q) {
+        const int it = D.adj_item[q], l = it >> 1, c = D.lcand[l];
+        const int f = D.lfrom[l], t = D.lto[l];
+        gk3_rz(D.cand, D.cstride, c, Rz, tz);
+        Edge3 E;
+        se3_edge(gk3_pose(D.X, D.ld, f), gk3_pose(D.X, D.ld, t), Rz, tz, E);
+        double Ja[6][6], Jb[6][6];
+        gk3_edge_J(E, Ja, Jb);
+        gk3_sym(D.cand, D.cstride, G_OM, c, om);
+        if (it & 1) gk3_atob(Jb, om, Jb, dg); else gk3_atob(Ja, om, Ja, dg);
+        const int other = (it & 1) ? f : t;
+        if (other >= 1 && other < p) {
+            double off[6][6] = {};
+            if (it & 1) gk3_atob(Jb, om, Ja, off); else gk3_atob(Ja, om, Jb, off);
+            put(p, other, off, true);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) Hd[(size_t)(6 * (p - 1) + c) * ldh + 6 * (p - 1) + r] = dg[r][c];
+        Hd[(size_t)(6 * (p - 1) + r) * ldh + n] = D.b[(size_t)r * D.ld + p];
+    }
+}
+__global__ void gk3_h_from_dense(ClusterDev3 D, const double* x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    if (i >= 1 && i <= D.L) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double hk = x[6 * (size_t)(i - 1) + k];
+            D.h[(size_t)k * D.ld + i] = hk;
+            v[0] += hk * hk;
+            v[1] += D.b[(size_t)k * D.ld + i] * hk;
+        }
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+__global__ void gk3_quad_bh(ClusterDev3 D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    int f = -1, t = -1;
+    double Rz[9], tz[3], om[21];
+    if (i >= 1 && i <= D.L) {
+        const int k = D.lo + i - 1;
+        f = i - 1; t = i;
+        gk3_rz(D.chain, D.estride, k, Rz, tz);
+        gk3_sym(D.chain, D.estride, G_OM, k, om);
+    } else if (i > D.L && i <= D.L + D.nl) {
+        const int l = i - D.L - 1, c = D.lcand[l];
+        f = D.lfrom[l]; t = D.lto[l];
+        gk3_rz(D.cand, D.cstride, c, Rz, tz);
+        gk3_sym(D.cand, D.cstride, G_OM, c, om);
+    }
+    if (f >= 0) {
+        Edge3 E;
+        se3_edge(gk3_pose(D.X, D.ld, f), gk3_pose(D.X, D.ld, t), Rz, tz, E);
+        double va[6] = {0, 0, 0, 0, 0, 0}, vb[6] = {0, 0, 0, 0, 0, 0}, wb[6], wh[6], o[6];
+        if (f > 0) gk3_ld6(D.b, D.ld, f, va);
+        if (t > 0) gk3_ld6(D.b, D.ld, t, vb);
+        se3_apply_J(E, va, vb, wb);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { va[k] = 0.0; vb[k] = 0.0; }
+        if (f > 0) gk3_ld6(D.h, D.ld, f, va);
+        if (t > 0) gk3_ld6(D.h, D.ld, t, vb);
+        se3_apply_J(E, va, vb, wh);
+        sym6_mul(om, wh, o);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[0] += wb[k] * o[k]; v[1] += wh[k] * o[k]; }
+    }
+    gk_block_reduce_store<2>(v, D.partial + blockIdx.x * 4);
+}
+
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
@@ -544,8 +699,12 @@ public:
     hipError_t trial(double p, double q, double& newChi, bool& anyChanged);
     void commit() { std::swap(dev_.X, dev_.Xn); std::swap(dev_.e, dev_.en); std::swap(dev_.le, dev_.len); }
     hipError_t max_edge_chi2(double& mx);
+    hipError_t damped_solve(double lambda, bool& ok, double& hh, double& bh, double& bHh, double& hHh);
+    bool allow_damping = true;          // Levenberg retry of a failed linear solve (dense normal equations, <= kMaxDenseN unknowns)
+    static constexpr int kMaxDenseN = 24000;
 
 private:
+    double* d_H_ = nullptr; size_t capH_ = 0;
     ClusterDev3 dev_{};
     hipStream_t st_ = nullptr;
     int nblk_ = 1;
@@ -559,7 +718,7 @@ private:
     void release()
     {
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_scal_);
-        hipFree(d_int_);
+        hipFree(d_int_); hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
         if (h_scal_) hipHostFree(h_scal_);
         d_edge_ = d_loop_ = d_S_ = d_partial_ = d_scal_ = nullptr; d_int_ = d_info_ = nullptr; h_scal_ = nullptr;
         capL_ = capNl_ = 0;
@@ -637,6 +796,36 @@ inline hipError_t ClusterSolver3::linearize(double& bb, double& bHb, double& hh,
     return hipSuccess;
 }
 
+inline hipError_t ClusterSolver3::damped_solve(double lambda, bool& ok, double& hh, double& bh, double& bHh, double& hHh)
+{
+    ClusterDev3& D = dev_;
+    const int n = 6 * D.L;
+    ok = false;
+    if (n > kMaxDenseN) return hipSuccess;
+    const size_t m = (size_t)(n + 1) * n;
+    if (2 * m > capH_) {
+        hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
+        IPC_CL_CHK(hipMalloc(&d_H_, sizeof(double) * 2 * m));
+        capH_ = 2 * m;
+    }
+    IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
+    IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
+    hipLaunchKernelGGL(gk3_dense_H, dim3((D.L + 1 + 63) / 64), dim3(64), 0, st_, D, d_H_, lambda);
+    IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));      // (solution in the scan workspace: 6 ld doubles)
+    hipLaunchKernelGGL(gk3_h_from_dense, dim3(nblk_), dim3(kGB), 0, st_, D, (const double*)D.sc);
+    sum_partials(2, 2);
+    hipLaunchKernelGGL(gk3_quad_bh, dim3(nblk_), dim3(kGB), 0, st_, D);
+    sum_partials(2, 4);
+    IPC_CL_CHK(hipGetLastError());
+    IPC_CL_CHK(fetch(6));
+    int info;
+    std::memcpy(&info, h_scal_ + 12, sizeof(int));
+    hh = h_scal_[2]; bh = h_scal_[3]; bHh = h_scal_[4]; hHh = h_scal_[5];
+    ok = info == 0 && hh == hh;
+    IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
+    return hipSuccess;
+}
+
 inline hipError_t ClusterSolver3::blend(double alpha, double& c, double& bma)
 {
     hipLaunchKernelGGL(gk3_blend, dim3(nblk_), dim3(kGB), 0, st_, dev_, alpha);
@@ -709,7 +898,7 @@ inline hipError_t ClusterSolver3::solve(hipStream_t st, const double* chain, int
                                 hipMemcpyDeviceToDevice, st));
     nblk_ = (L + nl + 1 + kGB - 1) / kGB;
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st));
-    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl);
+    return cluster_dogleg(*this, iterations, out, term_eps, tab_.L + tab_.nl, allow_damping);
 }
 
 }  // namespace ipc

@@ -550,6 +550,9 @@ struct ipc_engine {
     // device-resident dog-leg (cluster_persist.hpp): the default; IPC_CLUSTER_MODE=host keeps the host-driven kernels
     bool persist = true;
     bool last_persist = false;                         // which solver holds the poses of the last cluster solve
+    int* d_failed = nullptr; int last_lm_cells = 0;    // cells of the last solve redone with Levenberg damping
+    bool lm_retry = true;                              // IPC_LM_RETRY=0: a failed linear solve ends the optimisation (flags & 2), no damping
+    long lm_fallbacks = 0;
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
@@ -619,6 +622,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         }
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
+    if (const char* lm = getenv("IPC_LM_RETRY")) { if (*lm) h->lm_retry = atoi(lm) != 0; }
     {   // window: as many solves in flight as there are hardware queues to run them side by side (IPC_SPEC_WINDOW overrides)
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         h->spec_window = (q && atoi(q) >= 9) ? 8 : 4;
@@ -712,7 +716,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
-    hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+    hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc); hipFree(h->d_failed);
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
     delete h->cluster;
     delete h->cluster3;
@@ -914,18 +918,24 @@ static PoseArr pose_arr(double* base, int V);
 // SE3 [12][V]) on the engine's stream, by the device-resident dog-leg or (IPC_CLUSTER_MODE=host) the host-driven one.
 // Blocks until the result record is back; the optimised poses stay in the solver (cluster_result2 / cluster_result3).
 static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src, int lo, int hi, const std::vector<int>& members,
-                                int iters, ClusterOut& o)
+                                int iters, ClusterOut& o, bool force_host = false)
 {
-    h->last_persist = h->persist && PersistSolver<PersistSe2>::fits(hi - lo, (int)members.size());
+    h->last_persist = !force_host && h->persist && PersistSolver<PersistSe2>::fits(hi - lo, (int)members.size());
     if (h->last_persist) {
         if (h->dim == 3) {
             IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
                                            h->h_from.data(), h->h_to.data(), iters));
-            return h->persist3->wait(o);
+            IPC_CL_CHK(h->persist3->wait(o));
+        } else {
+            IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                           h->h_from.data(), h->h_to.data(), iters));
+            IPC_CL_CHK(h->persist2->wait(o));
         }
-        IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
-                                       h->h_from.data(), h->h_to.data(), iters));
-        return h->persist2->wait(o);
+        // a non-positive pivot in the capacitance factorisation: g2o would retry with Levenberg damping -- the
+        // host-driven solver does (dense normal equations), from the same start
+        if (!(o.flags & 2) || !h->lm_retry) return hipSuccess;
+        h->last_persist = false;
+        ++h->lm_fallbacks;
     }
     if (h->dim == 3)
         return h->cluster3->solve(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
@@ -978,6 +988,53 @@ static int solve_long_cells(ipc_engine* h, hipStream_t st, int nb, const unsigne
         HIPCHK(hipMemcpy(h->d_chi + offsets[s], chi.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_chitot + offsets[s], tot.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_meta + offsets[s], meta.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
+    }
+    return IPC_OK;
+}
+
+// Cells whose capacitance factorisation met a non-positive pivot (flags & 2: degenerate information matrices, NaN
+// poses): g2o retries such a solve with Levenberg damping.  The cell kernels cannot (see cluster_common.hpp), so the
+// few cells concerned are solved again by the host-driven cluster solver, which can -- same check, open-loop start.
+__global__ void k_collect_failed(int ncells, const int4* meta, int cap, int* list, int* count)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells || !(meta[c].z & 2)) return;
+    const int q = atomicAdd(count, 1);
+    if (q < cap) list[q] = c;
+}
+static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
+{
+    constexpr int kCap = 16384;
+    if (!h->d_failed) HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * (kCap + 1)));
+    HIPCHK(hipMemsetAsync(h->d_failed + kCap, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_collect_failed, dim3((total + 255) / 256), dim3(256), 0, st, total, (const int4*)h->d_meta, kCap,
+                       h->d_failed, h->d_failed + kCap);
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, h->d_failed + kCap, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->last_lm_cells = 0;
+    if (n == 0) return IPC_OK;
+    n = std::min(n, kCap);
+    if (int rc = ensure_incremental(h, "ipc_solve_rows")) return rc;
+    std::vector<int> idx(n);
+    HIPCHK(hipMemcpy(idx.data(), h->d_failed, sizeof(int) * n, hipMemcpyDeviceToHost));
+    std::sort(idx.begin(), idx.end());
+    for (int q = 0; q < n; ++q) {
+        int2 cell;
+        HIPCHK(hipMemcpy(&cell, h->d_cells + idx[q], sizeof(int2), hipMemcpyDeviceToHost));
+        const int i = cell.x, j = cell.y, nl = i == j ? 1 : 2;
+        const int lo = std::min(h->h_lo[i], h->h_lo[j]), hi = std::max(h->h_hi[i], h->h_hi[j]);
+        std::vector<int> members{i};
+        if (nl == 2) members.push_back(j);
+        int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
+        if ((hi - lo) + nl > 100) iters *= 5;                                  // consensus_utils.cpp:12-13
+        ClusterOut o;
+        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, true));
+        const int4 meta = make_int4(o.iterations, o.tries, o.flags, o.evals);
+        HIPCHK(hipMemcpy(h->d_chi + idx[q], &o.max_chi2, sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_chitot + idx[q], &o.chi2_total, sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_meta + idx[q], &meta, sizeof(int4), hipMemcpyHostToDevice));
+        ++h->last_lm_cells;
     }
     return IPC_OK;
 }
@@ -1098,6 +1155,9 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     h->last_launches = launches;
     h->last_cells = (int)total;
     h->last_long_cells = (int)n_long;
+    if (total && h->lm_retry) {
+        if (int rc = resolve_failed_cells(h, st, (int)total)) return rc;
+    }
     if (total)
         hipLaunchKernelGGL(k_scatter_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
                            h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, world, words,
@@ -1144,7 +1204,7 @@ extern "C" int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_ou
     const int N = h->N, words = (N + 63) / 64;
     const size_t need = (size_t)N * words;
     if (need > h->run_cap) {
-        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc); hipFree(h->d_failed);
         h->d_upper = h->d_bits = nullptr; h->d_acc = nullptr;
         HIPCHK(hipMalloc(&h->d_upper, sizeof(uint64_t) * need));
         HIPCHK(hipMalloc(&h->d_bits, sizeof(uint64_t) * need));
@@ -1226,6 +1286,7 @@ extern "C" int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out)
     out->failed_cells = (int)host[0];
     out->capped_cells = (int)host[1];
     out->nan_cells = (int)host[2];
+    out->damped_cells = h->last_lm_cells;
     return IPC_OK;
 }
 
@@ -1326,7 +1387,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
             HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 12 * (size_t)h->V));
             HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
         }
-        if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; }
+        if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; h->cluster3->allow_damping = h->lm_retry; }
         if (!h->persist3) {
             h->persist3 = new PersistSolver<PersistSe3>(); h->persist3->term_eps = h->term_eps; h->persist3->d_prof = h->d_prof;
             if (h->max_helpers >= 0) h->persist3->max_helpers = h->max_helpers;
@@ -1341,7 +1402,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         HIPCHK(hipMemcpyAsync(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
-    if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; }
+    if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; h->cluster->allow_damping = h->lm_retry; }
     if (!h->persist2) {
         h->persist2 = new PersistSolver<PersistSe2>(); h->persist2->term_eps = h->term_eps; h->persist2->d_prof = h->d_prof;
         if (h->max_helpers >= 0) h->persist2->max_helpers = h->max_helpers;
@@ -1525,9 +1586,34 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
     ipc_engine::SpecSlot& sl = h->slots[qk];
     ClusterOut o;
     HIPCHK(h->dim == 3 ? sl.s3->wait(o) : sl.s2->wait(o));
-    const bool agree = !(o.max_chi2 > sl.th);                                 // consensus_utils.cpp:17-21
     const int lo = sl.lo, hi = sl.hi, nclu = sl.nclu;
+    const double th = sl.th;
     sl.cand = -1;
+    if ((o.flags & 2) && h->lm_retry) {
+        // the capacitance factorisation met a non-positive pivot: redo this check with the host-driven solver, which
+        // retries with Levenberg damping as g2o does (rare: degenerate information matrices, NaN poses)
+        if (h->commit_count) HIPCHK(hipStreamWaitEvent(h->own_stream, h->ev_commit, 0));
+        const ClusterSpec c = cluster_of(h, k);
+        HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, c.lo, c.hi, c.members, c.iters, o));
+        const bool agree_lm = !(o.max_chi2 > th);
+        if (agree_lm) {
+            spec_invalidate(h, -1);
+            int rld = 0;
+            if (h->dim == 3) {
+                const double* res = cluster_result3(h, rld);
+                if (int rc = commit_accept(h, h->own_stream, k, lo, hi, nullptr, res, rld)) return rc;
+            } else {
+                const PoseArr X = cluster_result2(h);
+                if (int rc = commit_accept(h, h->own_stream, k, lo, hi, &X, nullptr, 0)) return rc;
+            }
+            HIPCHK(hipEventRecord(h->ev_commit, h->own_stream));
+            ++h->commit_count;
+        }
+        *agrees = agree_lm ? 1 : 0;
+        fill_info(info, lo, hi, nclu, o);
+        return IPC_OK;
+    }
+    const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
     if (agree) {                                                              // :69-71
         spec_invalidate(h, -1);
         if (h->dim == 3) {

@@ -270,3 +270,67 @@ def test_candidates_on_which_matrix_mode_and_the_reference_algorithm_differ(work
     assert only_faithful == want["accepted_by_the_reference_algorithm_only"], only_faithful
     # on these workloads the matrix mode is the more permissive of the two
     assert len(only_matrix) >= len(only_faithful)
+
+
+def _degenerate_graph():
+    """small_se2 + outliers with three odometry edges whose information has no rotational part (rank 2) and one with
+    no information at all: the covariance the capacitance formulation needs does not exist for them, g2o's normal
+    equations are still positive definite (or become so with Levenberg damping)."""
+    from ipc_amd import synth
+    g = synth.inject_outliers(synth.small_se2(), 6, seed=3)
+    oi = g.odom_info.copy()
+    for e in (12, 20, 31):
+        oi[e] = [oi[e][0], 0.0, 0.0, oi[e][3], 0.0, 0.0]
+    oi[40] = 0.0
+    g.odom_info = oi
+    return g
+
+
+def test_levenberg_retry_on_degenerate_information_matrix_mode(oracle):
+    """Cells whose capacitance factorisation fails are solved again with g2o's Levenberg retry on the literal normal
+    equations (reference behaviour behind src/consensus_utils.cpp:14, restated in oracle/ipc_oracle.c sub_optimize):
+    decisions equal to the oracle's, chi2 within 1e-5."""
+    from ipc_amd.consensus import IPC, Config, unpack_bits
+    O = oracle
+    g = _degenerate_graph()
+    cfg = Config()
+    eng = IPC(g, cfg, device=0)
+    bits, acc = eng.run()
+    rep = eng.solve_report()
+    assert rep["damped_cells"] > 0 and rep["failed_cells"] == 0, rep
+    ok, mx = O.consistency_matrix(2, g.odom_meas, g.odom_info, cfg.s_factor, g.loop_ids, g.loop_meas, g.loop_info,
+                                  cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base)
+    assert np.array_equal(unpack_bits(bits, eng.N), ok)
+    assert np.array_equal(acc, O.set_max(ok, O.candidate_order(g.loop_ids)))
+    cells = eng.cell_info()
+    ref = np.array([mx[c["i"], c["j"]] for c in cells])
+    rel = np.abs(cells["max_chi2"] - ref) / np.maximum(np.abs(ref), 1e-9)
+    done = (cells["flags"] & 1) != 0            # the dog-leg terminated; a cell cut off by the iteration cap on a still moving
+    assert rel[done].max() <= REL, (rel[done].max(), cells[done][np.argmax(rel[done])])    # (damped) trajectory depends on the path
+    assert rel.max() <= 1e-2, (rel.max(), cells[np.argmax(rel)])
+    # without the retry the same cells end in g2o's Fail state
+    e0 = _engine(g, cfg, "persist", IPC_LM_RETRY=0)
+    e0.run()
+    assert e0.solve_report()["failed_cells"] == rep["damped_cells"]
+
+
+@pytest.mark.parametrize("mode", ["persist", "host"])
+def test_levenberg_retry_on_degenerate_information_incremental(oracle, mode):
+    from ipc_amd.consensus import Config
+    O = oracle
+    g = _degenerate_graph()
+    cfg = Config()
+    eng = _engine(g, cfg, mode)
+    inc = O.IncrementalIPC(2, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                           cfg.slow_reject_th, cfg.slow_reject_iter_base, g.loop_ids, g.loop_meas, g.loop_info)
+    eng.reset()
+    damped = 0
+    for k in eng.candidate_order():
+        ok_ref, ref = inc.agreement_check(int(k))
+        ok, info = eng.agreementCheck(int(k), with_info=True)
+        assert ok == ok_ref, (k, ref, info.max_chi2)
+        assert abs(info.max_chi2 - ref["max_chi2"]) <= REL * max(abs(ref["max_chi2"]), 1e-9), (k, ref, info.max_chi2)
+        assert not (info.flags & 2)
+        damped += bool(info.flags & 4)
+    assert damped > 0
+    assert np.array_equal(eng.getMaxConsensusSet(), inc.consensus())
