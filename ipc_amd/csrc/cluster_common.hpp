@@ -140,8 +140,7 @@ struct LoopTables {
 //       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
 //       | damped_solve(lambda, ok, hh, bh, bHh, hHh)   (H + lambda I) h = b on the literal normal equations
 //
-// Levenberg retry of the linear solve (g2o OptimizationAlgorithmDogleg::solve, restated in oracle/ipc_oracle.c
-// sub_optimize): the Gauss-Newton step is first asked of the plain system; once a factorisation has met a
+// Levenberg retry of the linear solve (g2o OptimizationAlgorithmDogleg::solve, as the tests' CPU restatement follows it): the Gauss-Newton step is first asked of the plain system; once a factorisation has met a
 // non-positive pivot (`wasPD` false, sticky for the rest of the optimisation) every solve adds currentLambda to the
 // diagonal of H -- times 10 per failure up to 1e3, then Fail; divided by 5 (not below 1e-12) per success.  The
 // capacitance formulation of the cluster solvers cannot carry lambda (H + lambda I is not chain-structured in the
