@@ -99,14 +99,21 @@ int ipc_initial_poses(ipc_engine_t* h, double* poses_out);
 /* ---- consistency matrix (the batched form of
  *      isAgreeingWithCurrentState, reference src/consensus_utils.cpp:7-22) ------------------ */
 
-/* rows per rank of the row-cyclic shard: ceil(N / world). */
+/* rows per rank of a shard: ceil(N / world). */
 int ipc_rows_per_rank(int n, int world);
 
-/* Solve every cell (i, j >= i) whose row i satisfies i % world == rank.  d_upper is a device
- * buffer of ipc_rows_per_rank(N, world) * ceil(N/64) uint64 words; row r holds candidate
- * i = r*world + rank: bit j (j > i) = pair cell solved and consistent, bit i = diagonal cell
- * consistent.  Non-overlapping pairs are not solved (their bit stays 0; see
- * ipc_assemble_matrix). */
+/* Which rank solves which row of the matrix and where the row sits in that rank's shard: slot_out[i] = owner * rpr +
+ * index, rpr = ipc_rows_per_rank(n, world).  ids [n][2] as in ipc_set_candidates.  policy 0: row-cyclic (i % world);
+ * policy 1 (the engine's default, IPC_ROW_BALANCE=cost): balanced by cost -- a row's cost is the number of poses its
+ * cells sweep (sum over the overlapping pairs (i, j > i) of the union chain length + its own chain), rows go,
+ * costliest first, to the least loaded rank with a free slot.  Pure host code (no GPU): every rank of a distributed
+ * run computes the same map. */
+int ipc_row_assignment(int n, const int* ids, int world, int policy, int* slot_out);
+
+/* Solve every cell (i, j >= i) of the rows this rank owns (ipc_row_assignment with the engine's policy).  d_upper is a
+ * device buffer of ipc_rows_per_rank(N, world) * ceil(N/64) uint64 words; the row of candidate i sits at index
+ * slot[i] % rpr: bit j (j > i) = pair cell solved and consistent, bit i = diagonal cell consistent.  Non-overlapping
+ * pairs are not solved (their bit stays 0; see ipc_assemble_matrix). */
 int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream);
 /* Stream contract of ipc_solve_rows: the call enqueues on `stream` and on streams of the engine that
  * fork from / join back into it, and it blocks the HOST once (the cell count comes back from the
@@ -133,7 +140,7 @@ typedef struct {
 int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out);
 
 /* Build the full symmetric N x N bit matrix (row-major, ceil(N/64) words per row) from the
- * all-gathered shards d_gathered[world][rows_per_rank][words]:  C[i][j] = solved bit when the
+ * all-gathered shards d_gathered[world][rows_per_rank][words] (row i at gathered row slot[i]):  C[i][j] = solved bit when the
  * id intervals overlap with positive length (reference src/consensus.cpp:157-159), else
  * C[i][i] & C[j][j]. */
 int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, int world,
@@ -147,6 +154,13 @@ int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_accepted, vo
 /* Single-GPU convenience: solve + assemble + set-max, host outputs (any may be NULL):
  * bits_out [N][ceil(N/64)], accepted_out [N]. */
 int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_out);
+
+/* Matrix mode over several GPUs of one node from ONE process (what the reference's single-process testers need to use
+ * more than one GPU; a multi-process run gathers with RCCL instead, ipc_amd/dist.py).  engines[r], r < n_engines, were
+ * created on different devices with the same chain and given the same candidate list; engines[r] acts as rank r of
+ * world n_engines: all solve their rows concurrently, the shards are gathered onto engines[0]'s device by peer copies
+ * over xGMI, which assembles the matrix and runs the set-max.  Outputs as ipc_run. */
+int ipc_run_sharded(ipc_engine_t** engines, int n_engines, uint64_t* bits_out, uint8_t* accepted_out);
 
 /* Diagnostics of the last ipc_solve_rows(): number of solved cells, and their records. */
 int ipc_cell_count(ipc_engine_t* h, int* n_cells);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
-    "ipc_debug_dense_solve", "ipc_append_candidate",
+    "ipc_debug_dense_solve", "ipc_append_candidate", "ipc_row_assignment", "ipc_run_sharded",
 ]
 
 
@@ -87,10 +87,12 @@ def load():
     lib.ipc_candidate_order.argtypes = [vp, vp]
     lib.ipc_initial_poses.argtypes = [vp, vp]
     lib.ipc_rows_per_rank.argtypes = [ip, ip]
+    lib.ipc_row_assignment.argtypes = [ip, vp, ip, ip, vp]
     lib.ipc_solve_rows.argtypes = [vp, ip, ip, vp, vp]
     lib.ipc_assemble_matrix.argtypes = [vp, vp, ip, vp, vp]
     lib.ipc_set_max.argtypes = [vp, vp, vp, vp]
     lib.ipc_run.argtypes = [vp, vp, vp]
+    lib.ipc_run_sharded.argtypes = [C.POINTER(vp), ip, vp, vp]
     lib.ipc_cell_count.argtypes = [vp, C.POINTER(ip)]
     lib.ipc_cell_info.argtypes = [vp, vp, ip]
     lib.ipc_solve_report.argtypes = [vp, C.POINTER(SolveReport)]

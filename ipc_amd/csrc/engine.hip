@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ipc_amd.h"
@@ -221,14 +222,14 @@ __global__ void k_se3_propagate(int V, const double* rec, int stride, double* po
 // ------------------------------------------------------------------------------------------
 // counts layout: [2][kMaxBins+1][kPlanSub]  (0: diagonal cells, 1: pair cells; last slot = too long)
 constexpr int kPlanSub = 32;
-__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world, BinCaps bc,
+__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* slot, BinCaps bc,
                        unsigned* counters, const unsigned* offsets, int2* cells, int fill)
 {
     const int sub = (blockIdx.x + blockIdx.y) & (kPlanSub - 1);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;          // this thread's candidate, its interval read once
     const int loj = j < N ? lo[j] : 0, hij = j < N ? hi[j] : 0;
     for (int i = blockIdx.y; i < N; i += gridDim.y) {
-    if (i % world != rank) continue;
+    if (slot[i] / rpr != rank) continue;                          // rows of this rank (ipc_row_assignment)
     if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
     int slot = -1;
     if (j < N && j >= i) {
@@ -265,28 +266,28 @@ __global__ void k_plan(int N, const int* lo, const int* hi, int rank, int world,
 // results -> bits
 // ------------------------------------------------------------------------------------------
 __global__ void k_scatter_bits(int ncells, const int2* cells, const double* chi, double fast_th,
-                               double slow_th, int world, int words, unsigned long long* upper)
+                               double slow_th, int rpr, const int* slot, int words, unsigned long long* upper)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
     const int2 cc = cells[c];
     const double th = cc.x == cc.y ? fast_th : slow_th;
     const bool ok = !(chi[c] > th);                 // consensus_utils.cpp:18 (NaN agrees, as there)
-    if (ok) atomicOr(&upper[(size_t)(cc.x / world) * words + (cc.y >> 6)], 1ull << (cc.y & 63));
+    if (ok) atomicOr(&upper[(size_t)(slot[cc.x] % rpr) * words + (cc.y >> 6)], 1ull << (cc.y & 63));
 }
 
-// Symmetric N x N bit matrix from the gathered upper-triangle rows (row a of rank a % world at gathered row
-// (a % world) * rpr + a / world).  One wave per tile of 64 rows x one 64-bit word: lane l owns candidate j = 64 w + l
+// Symmetric N x N bit matrix from the gathered upper-triangle rows (row a at gathered row slot[a] = owner * rpr + its
+// index among the owner's rows, ipc_row_assignment).  One wave per tile of 64 rows x one 64-bit word: lane l owns candidate j = 64 w + l
 // (its interval and its diagonal bit), a row's overlap test is ONE compare per lane and a ballot, and the common
 // case -- no candidate of the word overlaps row i (reference src/consensus.cpp:157-159: then C[i][j] = C[i][i] & C[j][j])
 // -- is a single select of the word of diagonal bits; only overlapping pairs read their solved bit.
-__global__ __launch_bounds__(256) void k_assemble(int N, int words, int world, int rpr, const int* lo, const int* hi,
+__global__ __launch_bounds__(256) void k_assemble(int N, int words, const int* slot, const int* lo, const int* hi,
                                                   const unsigned long long* gathered, unsigned long long* bits)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = blockIdx.x;
     auto U = [&](int a, int c) -> unsigned {        // a <= c
-        const unsigned long long word = gathered[((size_t)(a % world) * rpr + a / world) * words + (c >> 6)];
+        const unsigned long long word = gathered[(size_t)slot[a] * words + (c >> 6)];
         return (unsigned)((word >> (c & 63)) & 1ull);
     };
     const int j = w * 64 + lane;
@@ -550,6 +551,7 @@ struct ipc_engine {
     // device-resident dog-leg (cluster_persist.hpp): the default; IPC_CLUSTER_MODE=host keeps the host-driven kernels
     bool persist = true;
     bool last_persist = false;                         // which solver holds the poses of the last cluster solve
+    int* d_slot = nullptr; int slot_world = 0; int row_policy = 1;    // row -> shard slot of the last world size (IPC_ROW_BALANCE=cyclic|cost)
     int* d_failed = nullptr; int last_lm_cells = 0;    // cells of the last solve redone with Levenberg damping
     bool lm_retry = true;                              // IPC_LM_RETRY=0: a failed linear solve ends the optimisation (flags & 2), no damping
     long lm_fallbacks = 0;
@@ -588,6 +590,48 @@ static int spec_quiesce(ipc_engine* h, bool state_changes);
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
+// Which rank solves which row, and where the row sits in that rank's shard: slot[i] = owner * rpr + index, rpr =
+// ipc_rows_per_rank(n, world).  policy 0: row-cyclic (i % world).  policy 1 (default): balanced by cost -- a row's
+// cost is the number of poses its cells sweep, sum over the overlapping pairs (i, j > i) of the union chain length
+// plus its own chain ("cost proportional to sum L, not to the row count"); rows go, costliest first, to
+// the least loaded rank that still has a free slot (ties: lower rank, then lower index).  Pure host code, no GPU: the
+// engine and every rank of a distributed run compute the same map from the same candidate list.
+extern "C" int ipc_row_assignment(int n, const int* ids, int world, int policy, int* slot_out)
+{
+    if (n < 0 || world < 1 || (n > 0 && (!ids || !slot_out))) return fail(IPC_ERR_ARG, "ipc_row_assignment: bad argument");
+    const int rpr = ipc_rows_per_rank(n, world);
+    if (policy == 0 || world == 1) {
+        for (int i = 0; i < n; ++i) slot_out[i] = (i % world) * rpr + i / world;
+        return IPC_OK;
+    }
+    std::vector<int> lo(n), hi(n);
+    for (int i = 0; i < n; ++i) { lo[i] = std::min(ids[2 * i], ids[2 * i + 1]); hi[i] = std::max(ids[2 * i], ids[2 * i + 1]); }
+    std::vector<long long> cost(n);
+    for (int i = 0; i < n; ++i) {
+        long long c = hi[i] - lo[i];
+        const int loi = lo[i], hii = hi[i];
+        for (int j = i + 1; j < n; ++j) {
+            const int a = std::max(loi, lo[j]), b = std::min(hii, hi[j]);
+            if (b - a > 0) c += std::max(hii, hi[j]) - std::min(loi, lo[j]);
+        }
+        cost[i] = c;
+    }
+    std::vector<int> rows(n);
+    std::iota(rows.begin(), rows.end(), 0);
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<long long> load(world, 0);
+    std::vector<int> used(world, 0);
+    for (int i : rows) {
+        int best = -1;
+        for (int r = 0; r < world; ++r)
+            if (used[r] < rpr && (best < 0 || load[r] < load[best])) best = r;
+        slot_out[i] = best * rpr + used[best];
+        ++used[best];
+        load[best] += cost[i];
+    }
+    return IPC_OK;
+}
+
 extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, const double* odom_info,
                           const ipc_params_t* params, int device, ipc_engine_t** out)
 {
@@ -623,6 +667,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
     if (const char* lm = getenv("IPC_LM_RETRY")) { if (*lm) h->lm_retry = atoi(lm) != 0; }
+    if (const char* rb = getenv("IPC_ROW_BALANCE")) {
+        if (!strcmp(rb, "cyclic")) h->row_policy = 0;
+        else if (*rb && strcmp(rb, "cost")) { delete h; return fail(IPC_ERR_ARG, "IPC_ROW_BALANCE must be 'cost' or 'cyclic'"); }
+    }
     {   // window: as many solves in flight as there are hardware queues to run them side by side (IPC_SPEC_WINDOW overrides)
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         h->spec_window = (q && atoi(q) >= 9) ? 8 : 4;
@@ -704,6 +752,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
 static void free_candidates(ipc_engine* h)
 {
     hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order); hipFree(h->d_live);
+    hipFree(h->d_slot); h->d_slot = nullptr; h->slot_world = 0;
     h->d_cand = nullptr; h->d_from = h->d_to = h->d_lo = h->d_hi = h->d_order = h->d_live = nullptr;
     h->N = 0;
 }
@@ -992,6 +1041,17 @@ static int solve_long_cells(ipc_engine* h, hipStream_t st, int nb, const unsigne
     return IPC_OK;
 }
 
+static int ensure_row_map(ipc_engine* h, int world)
+{
+    if (h->d_slot && h->slot_world == world) return IPC_OK;
+    std::vector<int> slot(h->N);
+    if (int rc = ipc_row_assignment(h->N, h->h_cand_ids.data(), world, h->row_policy, slot.data())) return rc;
+    if (!h->d_slot) HIPCHK(hipMalloc(&h->d_slot, sizeof(int) * h->N));
+    HIPCHK(hipMemcpy(h->d_slot, slot.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+    h->slot_world = world;
+    return IPC_OK;
+}
+
 // Cells whose capacitance factorisation met a non-positive pivot (flags & 2: degenerate information matrices, NaN
 // poses): g2o retries such a solve with Levenberg damping.  The cell kernels cannot (see cluster_common.hpp), so the
 // few cells concerned are solved again by the host-driven cluster solver, which can -- same check, open-loop start.
@@ -1048,6 +1108,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
+    if (int rc = ensure_row_map(h, world)) return rc;
     const BinCaps bc = h->plan.caps;
     const int nb = bc.n;
     constexpr int NS = 2 * (kMaxBins + 1);
@@ -1055,7 +1116,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     // pass 1: count
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
     const dim3 pgrid((N + 255) / 256, std::min(N, 2048)), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
                        h->d_offsets, (int2*)nullptr, 0);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
@@ -1087,7 +1148,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     // pass 2: fill
     HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, world, bc, h->d_counters,
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
                        h->d_offsets, h->d_cells, 1);
     HIPCHK(hipGetLastError());
     // solve: longest chains first
@@ -1160,7 +1221,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     }
     if (total)
         hipLaunchKernelGGL(k_scatter_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
-                           h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, world, words,
+                           h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, rpr, (const int*)h->d_slot, words,
                            (unsigned long long*)d_upper);
     HIPCHK(hipGetLastError());
     return IPC_OK;
@@ -1175,7 +1236,8 @@ extern "C" int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
-    hipLaunchKernelGGL(k_assemble, dim3(words, std::min((N + 255) / 256, 1024)), dim3(256), 0, st, N, words, world, rpr, h->d_lo,
+    if (int rc = ensure_row_map(h, world)) return rc;
+    hipLaunchKernelGGL(k_assemble, dim3(words, std::min((N + 255) / 256, 1024)), dim3(256), 0, st, N, words, (const int*)h->d_slot, h->d_lo,
                        h->d_hi, (const unsigned long long*)d_gathered, (unsigned long long*)d_bits);
     HIPCHK(hipGetLastError());
     return IPC_OK;
@@ -1204,7 +1266,7 @@ extern "C" int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_ou
     const int N = h->N, words = (N + 63) / 64;
     const size_t need = (size_t)N * words;
     if (need > h->run_cap) {
-        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc); hipFree(h->d_failed);
+        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
         h->d_upper = h->d_bits = nullptr; h->d_acc = nullptr;
         HIPCHK(hipMalloc(&h->d_upper, sizeof(uint64_t) * need));
         HIPCHK(hipMalloc(&h->d_bits, sizeof(uint64_t) * need));
@@ -1832,6 +1894,72 @@ extern "C" int ipc_debug_dense_solve(int n, const double* system, int mode, int 
     HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);
+    return IPC_OK;
+}
+
+// Matrix mode over several GPUs of one node from ONE process (the C++ testers' IPC_AMD_DEVICES): engines[r] hold the
+// same chain and candidate list on their own devices and act as rank r of world n_engines.  Every engine solves the
+// rows ipc_row_assignment gives it, concurrently (one host thread per device); the shards are copied into the gathered
+// layout on engines[0]'s device (hipMemcpyPeerAsync: xGMI peer copies, no collective library -- there is one gather,
+// not a reduction), which assembles the matrix and runs the set-max.  Outputs as ipc_run.
+extern "C" int ipc_run_sharded(ipc_engine_t** engines, int n_engines, uint64_t* bits_out, uint8_t* accepted_out)
+{
+    if (!engines || n_engines < 1) return fail(IPC_ERR_ARG, "ipc_run_sharded: no engines");
+    for (int r = 0; r < n_engines; ++r) {
+        if (!engines[r]) return fail(IPC_ERR_ARG, "ipc_run_sharded: engine %d is NULL", r);
+        if (engines[r]->N != engines[0]->N || engines[r]->V != engines[0]->V || engines[r]->dim != engines[0]->dim)
+            return fail(IPC_ERR_ARG, "ipc_run_sharded: engine %d holds a different problem", r);
+        if (engines[r]->h_cand_ids != engines[0]->h_cand_ids) return fail(IPC_ERR_ARG, "ipc_run_sharded: engine %d holds other candidates", r);
+    }
+    ipc_engine* h0 = engines[0];
+    if (h0->N <= 0) return fail(IPC_ERR_STATE, "ipc_run_sharded: no candidates set");
+    if (n_engines == 1) return ipc_run(h0, bits_out, accepted_out);
+    const int N = h0->N, words = (N + 63) / 64, world = n_engines, rpr = ipc_rows_per_rank(N, world);
+    const size_t shard = (size_t)rpr * words, need = (size_t)N * words;
+    HIPCHK(hipSetDevice(h0->device));
+    if (need > h0->run_cap) {
+        hipFree(h0->d_upper); hipFree(h0->d_bits); hipFree(h0->d_acc);
+        h0->d_upper = h0->d_bits = nullptr; h0->d_acc = nullptr;
+        HIPCHK(hipMalloc(&h0->d_upper, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h0->d_bits, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h0->d_acc, (size_t)N + 64));
+        h0->run_cap = need;
+    }
+    unsigned long long* d_gathered = nullptr;
+    HIPCHK(hipMalloc(&d_gathered, sizeof(uint64_t) * shard * world));
+    std::vector<int> rcs(world, IPC_OK);
+    std::vector<std::string> errs(world);
+    std::vector<std::thread> workers;
+    for (int r = 0; r < world; ++r) {
+        workers.emplace_back([&, r]() {
+            ipc_engine* h = engines[r];
+            auto bad = [&](hipError_t e, const char* what) {
+                if (e == hipSuccess) return false;
+                rcs[r] = IPC_ERR_HIP; errs[r] = std::string(what) + ": " + hipGetErrorString(e);
+                return true;
+            };
+            if (bad(hipSetDevice(h->device), "hipSetDevice")) return;
+            unsigned long long* d_shard = nullptr;
+            if (bad(hipMalloc(&d_shard, sizeof(uint64_t) * shard), "hipMalloc shard")) return;
+            const int rc = ipc_solve_rows(h, r, world, (uint64_t*)d_shard, h->own_stream);
+            if (rc) { rcs[r] = rc; errs[r] = ipc_last_error(); hipFree(d_shard); return; }
+            if (!bad(hipMemcpyPeerAsync(d_gathered + (size_t)r * shard, h0->device, d_shard, h->device, sizeof(uint64_t) * shard, h->own_stream),
+                     "hipMemcpyPeerAsync"))
+                bad(hipStreamSynchronize(h->own_stream), "hipStreamSynchronize");
+            hipFree(d_shard);
+        });
+    }
+    for (auto& w : workers) w.join();
+    HIPCHK(hipSetDevice(h0->device));
+    for (int r = 0; r < world; ++r)
+        if (rcs[r]) { hipFree(d_gathered); return fail((ipc_status)rcs[r], "ipc_run_sharded: rank %d: %s", r, errs[r].c_str()); }
+    int rc = ipc_assemble_matrix(h0, (const uint64_t*)d_gathered, world, (uint64_t*)h0->d_bits, h0->own_stream);
+    if (!rc) rc = ipc_set_max(h0, (const uint64_t*)h0->d_bits, h0->d_acc, h0->own_stream);
+    if (rc) { hipFree(d_gathered); return rc; }
+    HIPCHK(hipStreamSynchronize(h0->own_stream));
+    HIPCHK(hipFree(d_gathered));
+    if (bits_out) HIPCHK(hipMemcpy(bits_out, h0->d_bits, sizeof(uint64_t) * need, hipMemcpyDeviceToHost));
+    if (accepted_out) HIPCHK(hipMemcpy(accepted_out, h0->d_acc, (size_t)N, hipMemcpyDeviceToHost));
     return IPC_OK;
 }
 

@@ -167,9 +167,29 @@ IPC::IPC(const PoseGraph& g, const std::vector<Edge>& odom, const Config& cfg, i
     ipc_params_t p{cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base,
                    cfg.s_factor};
     check(ipc_create(_dim, _V, meas.data(), info.data(), &p, device, &_h));
+    // IPC_AMD_DEVICES=0,1,...: matrix mode sharded by rows over these GPUs from this one process (ipc_run_sharded);
+    // engine 0 is the one above, the others replicate the chain on their devices
+    if (const char* dv = std::getenv("IPC_AMD_DEVICES")) {
+        std::stringstream ss(dv);
+        std::string tok;
+        std::vector<int> devs;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+        if (devs.size() > 1) {
+            if (devs[0] != device) throw std::runtime_error("IPC_AMD_DEVICES must start with the engine's device");
+            for (size_t r = 1; r < devs.size(); ++r) {
+                ipc_engine_t* e = nullptr;
+                check(ipc_create(_dim, _V, meas.data(), info.data(), &p, devs[r], &e));
+                _replicas.push_back(e);
+            }
+        }
+    }
 }
 
-IPC::~IPC() { ipc_destroy(_h); }
+IPC::~IPC()
+{
+    for (ipc_engine_t* e : _replicas) ipc_destroy(e);
+    ipc_destroy(_h);
+}
 
 std::vector<uint8_t> IPC::agreementCheckAll(const std::vector<Edge>& cands)
 {
@@ -187,7 +207,15 @@ std::vector<uint8_t> IPC::agreementCheckAll(const std::vector<Edge>& cands)
     _order.assign(N, 0);
     _max_consensus_set.clear();
     if (N == 0) return acc;
-    check(ipc_run(_h, nullptr, acc.data()));
+    if (_replicas.empty()) check(ipc_run(_h, nullptr, acc.data()));
+    else {
+        std::vector<ipc_engine_t*> all{_h};
+        for (ipc_engine_t* e : _replicas) {
+            check(ipc_set_candidates(e, N, ids.data(), meas.data(), info.data()));
+            all.push_back(e);
+        }
+        check(ipc_run_sharded(all.data(), (int)all.size(), nullptr, acc.data()));
+    }
     ipc_solve_report_t rep{};
     check(ipc_solve_report(_h, &rep));
     if (rep.failed_cells || rep.long_cells)

@@ -84,6 +84,7 @@ public:
 private:
     void refreshConsensus();
     ipc_engine_t* _h = nullptr;
+    std::vector<ipc_engine_t*> _replicas;              // IPC_AMD_DEVICES: engines on the other GPUs (matrix mode, row shards)
     int _dim = 0, _V = 0;
     std::vector<int> _max_consensus_set, _order;
 };

@@ -1,7 +1,9 @@
 """world_size-2 run of the row-sharded matrix path on CPU (gloo): covers the shard layout, the
 all-gather and the reassembly + set-max plumbing of ipc_amd.dist without a GPU.  The solver
 backend is a stand-in built from the CPU oracle that emits exactly the shard format
-ipc_solve_rows() documents (include/ipc_amd.h)."""
+ipc_solve_rows() documents (include/ipc_amd.h); which rank owns which row, and where the row sits
+in its shard, comes from the library's own ipc_row_assignment() (host code of libipc_amd.so, the
+function the engine itself calls), cost-balanced policy."""
 import os
 import socket
 
@@ -33,21 +35,34 @@ class OracleBackend:
     def _overlap(self, i, j):
         return min(self.hi[i], self.hi[j]) - max(self.lo[i], self.lo[j]) > 0
 
+    def _slots(self, world):
+        import ctypes as C
+        from ipc_amd import capi
+        ids = np.ascontiguousarray(self.g.loop_ids, dtype=np.int32)
+        slot = np.zeros(self.N, dtype=np.int32)
+        capi.check(capi.load().ipc_row_assignment(self.N, ids.ctypes.data_as(C.c_void_p), world, 1,
+                                                  slot.ctypes.data_as(C.c_void_p)))
+        return slot
+
     def solve_rows(self, rank, world, upper):
         rpr = (self.N + world - 1) // world
+        slot = self._slots(world)
         u = np.zeros((rpr, self.words), dtype=np.uint64)
-        for i in range(rank, self.N, world):
+        for i in range(self.N):
+            if slot[i] // rpr != rank:
+                continue
             for j in range(i, self.N):
                 if (j == i or self._overlap(i, j)) and self.ok[i, j]:
-                    u[i // world, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+                    u[slot[i] % rpr, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
         upper.copy_(torch.from_numpy(u.view(np.int64).reshape(-1)))
 
     def assemble(self, gathered, world, bits):
         rpr = (self.N + world - 1) // world
-        ga = gathered.numpy().view(np.uint64).reshape(world, rpr, self.words)
+        slot = self._slots(world)
+        ga = gathered.numpy().view(np.uint64).reshape(world * rpr, self.words)
 
         def U(a, c):
-            return int((ga[a % world, a // world, c >> 6] >> np.uint64(c & 63)) & np.uint64(1))
+            return int((ga[slot[a], c >> 6] >> np.uint64(c & 63)) & np.uint64(1))
 
         out = np.zeros((self.N, self.words), dtype=np.uint64)
         for i in range(self.N):
@@ -131,3 +146,31 @@ def test_single_rank_path_needs_no_process_group():
     bits, acc = sm.result()
     assert np.array_equal(unpack_bits(bits, g.N), exp["okmat"])
     assert np.array_equal(acc, exp["accepted"])
+
+
+def test_row_assignment_is_a_balanced_partition():
+    """ipc_row_assignment: every row in exactly one slot, no rank beyond its rows_per_rank, and the cost policy's
+    heaviest rank within a few percent of the mean on a bench-size candidate list (the cyclic one is not)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    from ipc_amd import capi, synth
+    lib = capi.load()
+    g = synth.inject_outliers(synth.intel_like(), 1000, seed=1000)
+    ids = np.ascontiguousarray(g.loop_ids, dtype=np.int32)
+    lo, hi = ids.min(1), ids.max(1)
+    N = g.N
+    ov = (np.minimum(hi[:, None], hi[None, :]) - np.maximum(lo[:, None], lo[None, :])) > 0
+    union = np.maximum(hi[:, None], hi[None, :]) - np.minimum(lo[:, None], lo[None, :])
+    cost = (hi - lo) + np.triu(ov * union, k=1).sum(1)
+    for world in (2, 3, 8):
+        rpr = lib.ipc_rows_per_rank(N, world)
+        spread = {}
+        for policy in (0, 1):
+            slot = np.zeros(N, dtype=np.int32)
+            capi.check(lib.ipc_row_assignment(N, ids.ctypes.data_as(C.c_void_p), world, policy, slot.ctypes.data_as(C.c_void_p)))
+            assert len(set(slot.tolist())) == N and slot.min() >= 0 and slot.max() < world * rpr
+            load = np.bincount(slot // rpr, weights=cost, minlength=world)
+            spread[policy] = load.max() / load.mean()
+        assert spread[1] <= 1.01, spread
+        assert spread[1] <= spread[0]

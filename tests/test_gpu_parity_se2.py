@@ -1,4 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -371,3 +373,33 @@ def test_row_shards_reassemble_to_the_single_gpu_matrix(oracle, world):
     got = bits.cpu().numpy().view(np.uint64).reshape(eng.N, eng.words)
     assert np.array_equal(got, ref_bits)
     assert np.array_equal(acc.cpu().numpy(), ref_acc)
+
+
+@pytest.mark.parametrize("n_engines", [2, 3])
+def test_run_sharded_from_one_process_equals_the_single_engine_run(n_engines):
+    """ipc_run_sharded (the C++ testers' multi-GPU path: one process, one engine per device, peer copies of the shards,
+    cost-balanced rows) -- here with every engine on device 0, which exercises everything but the xGMI hop."""
+    import ctypes as C
+    from ipc_amd import capi, synth
+    from ipc_amd.consensus import IPC, Config
+    g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
+    cfg = Config()
+    engines = [IPC(g, cfg, device=0) for _ in range(n_engines)]
+    ref_bits, ref_acc = engines[0].run()
+    lib = capi.load()
+    arr = (C.c_void_p * n_engines)(*[e.h for e in engines])
+    bits = np.zeros((g.N, engines[0].words), dtype=np.uint64)
+    acc = np.zeros(g.N, dtype=np.uint8)
+    capi.check(lib.ipc_run_sharded(arr, n_engines, bits.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(bits, ref_bits) and np.array_equal(acc, ref_acc)
+    # both row policies give the same matrix
+    for pol in ("cyclic", "cost"):
+        os.environ["IPC_ROW_BALANCE"] = pol
+        try:
+            es = [IPC(g, cfg, device=0) for _ in range(2)]
+        finally:
+            del os.environ["IPC_ROW_BALANCE"]
+        arr2 = (C.c_void_p * 2)(*[e.h for e in es])
+        b2 = np.zeros_like(bits)
+        capi.check(lib.ipc_run_sharded(arr2, 2, b2.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(b2, ref_bits) and np.array_equal(acc, ref_acc)

@@ -1,6 +1,6 @@
 """Per-rank solve time of the row shards, emulated on ONE GPU (each rank's shard solved in turn;
-no collective): shows the load balance of the row-cyclic partition and the fixed per-step cost.
-usage: python tools/shard_balance.py [C2] [world ...]"""
+no collective): shows the load balance of the row partition (IPC_ROW_BALANCE=cost|cyclic) and the fixed per-step cost.
+usage: [IPC_ROW_BALANCE=cyclic] python tools/shard_balance.py [C2] [world ...]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
