@@ -398,6 +398,18 @@ def main():
             n_inc = N if g.dim == 2 and args.workload in ("C1", "C2", "tiny", "T700") else 0
         if n_inc > 0:
             out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5, args.workload)
+    if rank == 0 and world == 1:
+        # reported separately, never the headline: the accepted SET without the cells the set-max never reads
+        # (ipc_run_set_only: diagonal cells first, then the pairs among the candidates whose own cell passed)
+        eng.run_set_only()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            acc_so, n_so = eng.run_set_only()
+        eng.synchronize()
+        t_so = (time.perf_counter() - t0) / 3
+        out["set_only_mode"] = {"ms_per_run": t_so * 1e3, "solved_cells": int(n_so), "same_set_as_the_matrix": bool(np.array_equal(acc_so, acc)),
+                                "note": "not the metric: no consistency matrix comes out of this mode, only the accepted set"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -155,6 +155,12 @@ int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_accepted, vo
  * bits_out [N][ceil(N/64)], accepted_out [N]. */
 int ipc_run(ipc_engine_t* h, uint64_t* bits_out, uint8_t* accepted_out);
 
+/* Set-only mode (one GPU): the accepted set of ipc_run without the cells the set-max never reads -- the diagonal cells
+ * first, then the pair cells among the candidates whose own cell passed (SURVEY.md 8a row P2 only ever tests those).
+ * Same accepted set as ipc_run by construction; no consistency matrix comes out of it (reported separately from the
+ * candidate-pairs/s metric, which is defined over the full matrix).  *solved_cells_out: cells actually solved. */
+int ipc_run_set_only(ipc_engine_t* h, uint8_t* accepted_out, int* solved_cells_out);
+
 /* Matrix mode over several GPUs of one node from ONE process (what the reference's single-process testers need to use
  * more than one GPU; a multi-process run gathers with RCCL instead, ipc_amd/dist.py).  engines[r], r < n_engines, were
  * created on different devices with the same chain and given the same candidate list; engines[r] acts as rank r of

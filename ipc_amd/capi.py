@@ -24,7 +24,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
-    "ipc_debug_dense_solve", "ipc_append_candidate", "ipc_row_assignment", "ipc_run_sharded",
+    "ipc_debug_dense_solve", "ipc_append_candidate", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.ipc_set_max.argtypes = [vp, vp, vp, vp]
     lib.ipc_run.argtypes = [vp, vp, vp]
     lib.ipc_run_sharded.argtypes = [C.POINTER(vp), ip, vp, vp]
+    lib.ipc_run_set_only.argtypes = [vp, vp, C.POINTER(ip)]
     lib.ipc_cell_count.argtypes = [vp, C.POINTER(ip)]
     lib.ipc_cell_info.argtypes = [vp, vp, ip]
     lib.ipc_solve_report.argtypes = [vp, C.POINTER(SolveReport)]

@@ -85,6 +85,16 @@ class IPC:
         self._max_consensus_set = order[acc[order] == 1]
         return bits, acc
 
+    def run_set_only(self):
+        """The accepted set of run() without the cells the set-max never reads (diagonal first, then the pairs among the
+        candidates whose own cell passed); returns (accepted [N] uint8, cells actually solved)."""
+        acc = np.zeros(self.N, dtype=np.uint8)
+        n = C.c_int(0)
+        capi.check(self.lib.ipc_run_set_only(self.h, _p(acc), C.byref(n)))
+        order = self.candidate_order()
+        self._max_consensus_set = order[acc[order] == 1]
+        return acc, n.value
+
     def consistency_matrix(self):
         bits, _ = self.run()
         return unpack_bits(bits, self.N)

@@ -222,20 +222,25 @@ __global__ void k_se3_propagate(int V, const double* rec, int stride, double* po
 // ------------------------------------------------------------------------------------------
 // counts layout: [2][kMaxBins+1][kPlanSub]  (0: diagonal cells, 1: pair cells; last slot = too long)
 constexpr int kPlanSub = 32;
-__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* slot, BinCaps bc,
-                       unsigned* counters, const unsigned* offsets, int2* cells, int fill)
+// phase 0: every cell of this rank's rows; 1: the diagonal cells only; 2: the pair cells of candidates whose own cell
+// passed (diagonal bit set in `diag`, the shard of a one-rank run) -- the set-only mode of ipc_run_set_only
+__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* rowslot, BinCaps bc,
+                       unsigned* counters, const unsigned* offsets, int2* cells, int fill, int phase = 0,
+                       const unsigned long long* diag = nullptr, int words = 0)
 {
     const int sub = (blockIdx.x + blockIdx.y) & (kPlanSub - 1);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;          // this thread's candidate, its interval read once
     const int loj = j < N ? lo[j] : 0, hij = j < N ? hi[j] : 0;
+    const bool alivej = phase != 2 || (j < N && ((diag[(size_t)j * words + (j >> 6)] >> (j & 63)) & 1ull));
     for (int i = blockIdx.y; i < N; i += gridDim.y) {
-    if (slot[i] / rpr != rank) continue;                          // rows of this rank (ipc_row_assignment)
+    if (rowslot[i] / rpr != rank) continue;                       // rows of this rank (ipc_row_assignment)
+    if (phase == 2 && !((diag[(size_t)i * words + (i >> 6)] >> (i & 63)) & 1ull)) continue;
     if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
     int slot = -1;
     if (j < N && j >= i) {
         const int loi = lo[i], hii = hi[i];
-        if (j == i) slot = bin_of(bc, hii - loi);
-        else {
+        if (j == i) { if (phase != 2) slot = bin_of(bc, hii - loi); }
+        else if (phase != 1 && alivej) {
             if (min(hii, hij) - max(loi, loj) > 0)            // reference src/consensus.cpp:157-159
                 slot = (kMaxBins + 1) + bin_of(bc, max(hii, hij) - min(loi, loj));
         }
@@ -1099,12 +1104,21 @@ static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
     return IPC_OK;
 }
 
+static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper, void* stream, int phase);
+
 extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_solve_rows: NULL handle");
     if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_solve_rows: no candidates set");
     if (world < 1 || rank < 0 || rank >= world) return fail(IPC_ERR_ARG, "ipc_solve_rows: rank %d of %d", rank, world);
     if (!d_upper) return fail(IPC_ERR_ARG, "ipc_solve_rows: d_upper is NULL");
+    return solve_rows_impl(h, rank, world, d_upper, stream, 0);
+}
+
+// phase 0: all cells of the rank's rows.  Set-only mode (one rank): phase 1 = the diagonal cells, phase 2 = the pair cells
+// among the candidates whose diagonal bit is set in d_upper (left in place; the pair bits are OR-ed into it).
+static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper, void* stream, int phase)
+{
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
@@ -1112,12 +1126,12 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     const BinCaps bc = h->plan.caps;
     const int nb = bc.n;
     constexpr int NS = 2 * (kMaxBins + 1);
-    HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
+    if (phase != 2) HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
     // pass 1: count
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
     const dim3 pgrid((N + 255) / 256, std::min(N, 2048)), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
     hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
-                       h->d_offsets, (int2*)nullptr, 0);
+                       h->d_offsets, (int2*)nullptr, 0, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
     static thread_local unsigned subcounts[NS * kPlanSub], suboffsets[NS * kPlanSub];
@@ -1149,7 +1163,7 @@ extern "C" int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_
     HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
     hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
-                       h->d_offsets, h->d_cells, 1);
+                       h->d_offsets, h->d_cells, 1, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     // solve: longest chains first
     const Se2View P = make_view(h);
@@ -1894,6 +1908,38 @@ extern "C" int ipc_debug_dense_solve(int n, const double* system, int mode, int 
     HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);
+    return IPC_OK;
+}
+
+// Set-only mode (one GPU): the consensus set of the batched formulation without the cells the set-max never reads.
+// ipc_set_max only ever tests candidates whose own (diagonal) cell passed, and for those only their bits against each
+// other: so the diagonal cells are solved first, then the pair cells among the candidates that passed.  Same accepted
+// set as ipc_run by construction (tests hold them against each other); the bit matrix it builds on the way is NOT the
+// consistency matrix (pairs with a failed candidate stay unsolved) and is not returned.
+extern "C" int ipc_run_set_only(ipc_engine_t* h, uint8_t* accepted_out, int* solved_cells_out)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_run_set_only: NULL handle");
+    if (h->N <= 0) return fail(IPC_ERR_STATE, "ipc_run_set_only: no candidates set");
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->N, words = (N + 63) / 64;
+    const size_t need = (size_t)N * words;
+    if (need > h->run_cap) {
+        hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc);
+        h->d_upper = h->d_bits = nullptr; h->d_acc = nullptr;
+        HIPCHK(hipMalloc(&h->d_upper, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h->d_bits, sizeof(uint64_t) * need));
+        HIPCHK(hipMalloc(&h->d_acc, (size_t)N + 64));
+        h->run_cap = need;
+    }
+    int rc = solve_rows_impl(h, 0, 1, (uint64_t*)h->d_upper, h->own_stream, 1);
+    const int diag_cells = h->last_cells;
+    if (!rc) rc = solve_rows_impl(h, 0, 1, (uint64_t*)h->d_upper, h->own_stream, 2);
+    if (!rc) rc = ipc_assemble_matrix(h, (const uint64_t*)h->d_upper, 1, (uint64_t*)h->d_bits, h->own_stream);
+    if (!rc) rc = ipc_set_max(h, (const uint64_t*)h->d_bits, h->d_acc, h->own_stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->own_stream));
+    if (solved_cells_out) *solved_cells_out = diag_cells + h->last_cells;
+    if (accepted_out) HIPCHK(hipMemcpy(accepted_out, h->d_acc, (size_t)N, hipMemcpyDeviceToHost));
     return IPC_OK;
 }
 

@@ -403,3 +403,21 @@ def test_run_sharded_from_one_process_equals_the_single_engine_run(n_engines):
         b2 = np.zeros_like(bits)
         capi.check(lib.ipc_run_sharded(arr2, 2, b2.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p)))
         assert np.array_equal(b2, ref_bits) and np.array_equal(acc, ref_acc)
+
+
+@pytest.mark.parametrize("workload", ["tiny", "T700", "C1", "C2", "C4s"])
+def test_set_only_mode_returns_the_set_of_the_full_matrix(workload):
+    """ipc_run_set_only solves the diagonal first and then only the pair cells among the candidates whose own cell
+    passed (the only bits the set-max reads): same accepted set as the full matrix, a fraction of the cells."""
+    import bench
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = bench.build_workload(workload)
+    eng = IPC(g, cfg, device=0)
+    _, acc = eng.run()
+    n_full = len(eng.cell_info())
+    acc2, n_set = eng.run_set_only()
+    assert np.array_equal(acc, acc2)
+    assert n_set <= n_full
+    if workload == "C2":
+        assert n_set * 5 < n_full
+    assert np.array_equal(eng.getMaxConsensusSet(), eng.candidate_order()[acc[eng.candidate_order()] == 1])
