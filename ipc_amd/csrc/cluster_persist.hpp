@@ -25,7 +25,9 @@
 
 namespace ipc {
 
-constexpr int kPT = 512;                     // threads per workgroup (256 VGPRs per thread: the tile update and the SE3 phases need them)
+constexpr int kPT = 512;                     // threads per workgroup: 8 waves = 2 per SIMD = 256 VGPRs per lane, which the panel solve and
+                                             // the tile update need (768 threads / 168 VGPRs: the leader's phases take two passes instead of three
+                                             // over a 1 500-pose chain, but the panel solve spills and a block column costs 2.5x -- measured, dropped)
 constexpr int kPSG = kPT / 256;              // 256-thread sub-groups (one 64 x 64 tile each)
 constexpr unsigned kSpinLimit = 1u << 21;    // polls before a barrier gives up (seconds): a lost workgroup must not hang the GPU
 
@@ -59,9 +61,9 @@ constexpr int kLdsDinv = kCB * (kCB + 1);                  // [32]
 constexpr int kLdsR = kLdsDinv + kCB;                      // phase-private region
 constexpr int kLdsPanel = kCB * (64 + 1);                  // one [32][65] panel
 constexpr int kLdsTotal = kLdsR + kPSG * 2 * kLdsPanel;    // 17 728 doubles = 141 824 bytes
-// leader's use of the region: reduction staging [kLeadMaxBlk runs][4 waves][2], results [8], scan partials [9][16]
+// leader's use of the region: reduction staging [kLeadMaxBlk runs][4 waves][2], results [8], scan partials [9][32]
 constexpr int kLeadMaxBlk = 700;            // runs of 256 indices the reduction staging holds (L + nl < 179 200)
-constexpr int kLdsRed = kLdsR, kLdsRes = kLdsRed + kLeadMaxBlk * 4 * 2, kLdsWsum = kLdsRes + 8, kLdsMisc = kLdsWsum + 9 * 16;
+constexpr int kLdsRed = kLdsR, kLdsRes = kLdsRed + kLeadMaxBlk * 4 * 2, kLdsWsum = kLdsRes + 8, kLdsMisc = kLdsWsum + 9 * 32;
 static_assert(kLdsMisc + 64 <= kLdsTotal, "LDS carve-up");
 
 struct GridBar { unsigned* ctr; unsigned target; int G; int* error; unsigned long long* prof; };
@@ -151,9 +153,9 @@ __device__ __forceinline__ void lead_reduce(int nblk, double* lds, double (&tot)
 template <int K>
 __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* lds)
 {
-    constexpr int NP = 1024 / kPT, NW = kPT / 64;
+    constexpr int NP = (1024 + kPT - 1) / kPT;               // passes of the workgroup over a run of 1024 indices
     double* wsum = lds + kLdsWsum;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     double carry[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) carry[k] = 0.0;
@@ -161,13 +163,15 @@ __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* 
         double v[NP][K];
 #pragma unroll
         for (int hp = 0; hp < NP; ++hp) {
-            const int i = base + hp * kPT + tid;
-            const int ic = i <= L ? i : 0;                    // (index 0 is a valid, unused slot of every row: no predicated loads)
+            const int off = hp * kPT + tid;                   // position in the run; its wave of 64 is off >> 6
+            const int i = base + off;
+            const bool in = off < 1024 && i <= L;
+            const int ic = in ? i : 0;                        // (index 0 is a valid, unused slot of every row: no predicated loads)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double a = arr[(size_t)k * ld + ic];
-                v[hp][k] = wave_inclusive_scan(i <= L ? a : 0.0);
-                wsum[k * 16 + hp * NW + wave] = read_lane(v[hp][k], 63);      // (uniform value, every lane stores it)
+                v[hp][k] = wave_inclusive_scan(in ? a : 0.0);
+                wsum[k * 32 + (off >> 6)] = read_lane(v[hp][k], 63);      // (uniform value, every lane stores it; slots >= 16 are never summed)
             }
         }
         __syncthreads();
@@ -175,20 +179,20 @@ __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* 
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             double tt = carry[k];
-            for (int w = 0; w < 16; ++w) tt += wsum[k * 16 + w];
+            for (int w = 0; w < 16; ++w) tt += wsum[k * 32 + w];
 #pragma unroll
             for (int hp = 0; hp < NP; ++hp) {
-                const int vw = hp * NW + wave;
+                const int vw = (hp * kPT + tid) >> 6;
                 double off = carry[k];
-                for (int w = 0; w < vw; ++w) off += wsum[k * 16 + w];
+                for (int w = 0; w < vw && w < 16; ++w) off += wsum[k * 32 + w];
                 res[hp][k] = v[hp][k] + off;
             }
             carry[k] = tt;
         }
 #pragma unroll
         for (int hp = 0; hp < NP; ++hp) {
-            const int i = base + hp * kPT + tid;
-            if (i <= L) {                                     // (one branch around the K stores)
+            const int off = hp * kPT + tid, i = base + off;
+            if (off < 1024 && i <= L) {                       // (one branch around the K stores)
 #pragma unroll
                 for (int k = 0; k < K; ++k) arr[(size_t)k * ld + i] = res[hp][k];
             }
@@ -514,7 +518,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
 // so a step costs its arithmetic, not a round trip to memory per phase.  x also lives in LDS while it fits.
 __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x, double* lds)
 {
-    constexpr int NW = kPT / 64, CPW = kCB / NW, MAXM = 12, DPT = kCB * kCB / kPT;
+    constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 12, DPT = (kCB * kCB + kPT - 1) / kPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
     double* t = lds + kLdsDinv;
     double* xs = lds + kLdsR;
@@ -537,7 +541,7 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
-            dpre[q] = ld_shared(&Lf[(r < nb && c < nb && r >= c) ? (size_t)(k0 + c) * ld + k0 + r : (size_t)0]);
+            dpre[q] = ld_shared(&Lf[(idx < kCB * kCB && r < nb && c < nb && r >= c) ? (size_t)(k0 + c) * ld + k0 + r : (size_t)0]);
         }
         ypre = ld_shared(&Lf[l < nb ? (size_t)(k0 + l) * ld + n : (size_t)0]);
     };
@@ -563,7 +567,7 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
-            D[r][c] = (r < nb && c < nb && r >= c) ? dpre[q] : (r == c ? 1.0 : 0.0);
+            if (idx < kCB * kCB) D[r][c] = (r < nb && c < nb && r >= c) ? dpre[q] : (r == c ? 1.0 : 0.0);
         }
         const double ycur = ypre;
         if (kb > 0) prefetch(kb - 1);
