@@ -23,6 +23,13 @@ constexpr int kGB = 256;                     // threads per block of the grid ke
 // kernel, cluster_persist.hpp): agent-scope relaxed atomics = global_load / global_store ... sc1, which bypass the
 // CU's L1 and write through the XCD's L2 (per-XCD L2s are not coherent with each other), so that no cache
 // write-back / invalidate is needed around the grid barriers.  In the one-kernel-per-phase path they cost nothing.
+// A pointer known to point into global memory.  The cluster solvers' arrays hang off a struct; where that struct is read
+// through a pointer (the persistent kernel switches between two views of it) the compiler no longer knows the address
+// space of its members and emits flat loads, which count against both vmcnt and lgkmcnt and so can only be waited for
+// all at once.  Indexed through this cast they are global loads / stores again.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* gptr(T* p) { return (__attribute__((address_space(1))) T*)p; }
+
 __device__ __forceinline__ double ld_shared(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_shared(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

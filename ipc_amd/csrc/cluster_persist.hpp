@@ -71,7 +71,7 @@ struct GridBar { unsigned* ctr; unsigned target; int G; int* error; unsigned lon
 // phase clocks (thread 0 of workgroup 0 only; prof == nullptr: off)
 enum { kProfTotal = 0, kProfPre, kProfHandoff, kProfAssemble, kProfFactor, kProfFactorWork, kProfFactorWait, kProfBacksolve,
        kProfPost, kProfTrial, kProfRest, kProfIterations, kProfSteps,
-       kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfN };
+       kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfBsDots, kProfBsPrefetch, kProfBsSync, kProfBsTri, kProfN };
 __device__ __forceinline__ unsigned long long prof_now() { return wall_clock64(); }
 __device__ __forceinline__ void prof_add(unsigned long long* prof, int slot, unsigned long long t0)
 {
@@ -169,7 +169,7 @@ __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* 
             const int ic = in ? i : 0;                        // (index 0 is a valid, unused slot of every row: no predicated loads)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const double a = arr[(size_t)k * ld + ic];
+                const double a = gptr(arr)[(size_t)k * ld + ic];
                 v[hp][k] = wave_inclusive_scan(in ? a : 0.0);
                 wsum[k * 32 + (off >> 6)] = read_lane(v[hp][k], 63);      // (uniform value, every lane stores it; slots >= 16 are never summed)
             }
@@ -194,7 +194,7 @@ __device__ __forceinline__ void lead_scan_k(double* arr, int L, int ld, double* 
             const int off = hp * kPT + tid, i = base + off;
             if (off < 1024 && i <= L) {                       // (one branch around the K stores)
 #pragma unroll
-                for (int k = 0; k < K; ++k) arr[(size_t)k * ld + i] = res[hp][k];
+                for (int k = 0; k < K; ++k) gptr(arr)[(size_t)k * ld + i] = res[hp][k];
             }
         }
         __syncthreads();
@@ -262,7 +262,7 @@ __device__ __forceinline__ void publish_block(double (*Dn)[kCB + 1], const doubl
 // (a dot-product form's order, without its dependent chain); the block's columns come from LDS at uniform addresses
 // (broadcast reads).
 typedef __attribute__((address_space(3))) const double lds_cdouble;
-template <class Store>
+template <bool DOUBLE_BUFFER, class Store>
 __device__ __forceinline__ void trsm32(double (&x)[kCB], const double* DT_generic, Store store)
 {
     // The block's LDS address goes through a register the compiler cannot see into: with a link-time constant base
@@ -276,16 +276,23 @@ __device__ __forceinline__ void trsm32(double (&x)[kCB], const double* DT_generi
     for (int c = 0; c < kCB; ++c) cur[c] = DT[c];
 #pragma unroll
     for (int p = 0; p < kCB; ++p) {
+        // The next column of the block is requested as ONE batch (left alone, the scheduler sinks every read next to its
+        // use: read, wait, two FMAs, read, wait ...).  DOUBLE_BUFFER: before this column's products, into a second set of
+        // registers -- its LDS latency hides behind them (workgroup 0's look-ahead, which has the registers); otherwise
+        // right behind the products into the registers of the column just applied (the tiles: a second buffer spilled).
+        double nxt[kCB];
+        if (DOUBLE_BUFFER) {
+#pragma unroll
+            for (int c = p + 1; c < kCB; ++c) nxt[c] = DT[(p + 1) * kCB + c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         x[p] = x[p] * cur[p];
 #pragma unroll
         for (int c = p + 1; c < kCB; ++c) x[c] -= x[p] * cur[c];
         store(p, x[p]);
-        // The next column of the block is requested as one batch right behind the products (left alone, the scheduler
-        // sinks every read next to its use: read, wait, two FMAs, read, wait ...); it lands in the registers of the
-        // column just applied, so the solve holds x and one column: a second buffer spilled.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = p + 1; c < kCB; ++c) cur[c] = DT[(p + 1) * kCB + c];
+        for (int c = p + 1; c < kCB; ++c) cur[c] = DOUBLE_BUFFER ? nxt[c] : DT[(p + 1) * kCB + c];
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -314,7 +321,7 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
 #pragma unroll
         for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
         double (*P)[64 + 1] = wv == 0 ? Ai : Aj;
-        trsm32(x, DT, [&](int p, double v) { P[p][lane] = p < nb ? v : 0.0; });
+        trsm32<false>(x, DT, [&](int p, double v) { P[p][lane] = p < nb ? v : 0.0; });
         // (one branch around all the stores: a conditional store per column splits the unrolled solve into 32 blocks
         // and the register allocator gives up -- 1.5 KB of scratch per lane)
         if (wv == 0 && by == 0 && pvalid) {
@@ -472,7 +479,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
 #pragma unroll
                     for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
                     prof_add(gb.prof, kProfLookLoad, tl0); tl0 = prof_now();
-                    trsm32(x, DT, [&](int p, double v) { Lrow[p][lane] = p < nb ? v : 0.0; });
+                    trsm32<true>(x, DT, [&](int p, double v) { Lrow[p][lane] = p < nb ? v : 0.0; });
                 }
                 // identity padding / zeros above the diagonal, then the lower triangle on top
                 for (int idx = tid; idx < kCB * kCB; idx += kPT) Dn[idx >> 5][idx & 31] = (idx >> 5) == (idx & 31) ? 1.0 : 0.0;
@@ -516,7 +523,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
 // factor's entries of block column kb-1 (4 columns per wave, the first 768 rows below the block; its diagonal block;
 // its right-hand side) are requested BEFORE the triangle of block column kb is solved -- they do not depend on x --
 // so a step costs its arithmetic, not a round trip to memory per phase.  x also lives in LDS while it fits.
-__device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x, double* lds)
+__device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x, double* lds, unsigned long long* prof = nullptr)
 {
     constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 12, DPT = (kCB * kCB + kPT - 1) / kPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
@@ -529,13 +536,18 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
     double pre[CPW][MAXM], dpre[DPT], ypre = 0.0;
     auto prefetch = [&](int kb) {
         const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
+        const double* colp[CPW];
 #pragma unroll
         for (int q = 0; q < CPW; ++q) {
-            const int c = wave + q * NW;
+            const int c = min(wave + q * NW, nb - 1);         // (columns beyond a short block: a valid one, result unused)
+            colp[q] = Lf + (size_t)(k0 + c) * ld + k1 + lane;
+        }
 #pragma unroll
-            for (int m = 0; m < MAXM; ++m) {
-                const int r = k1 + lane + 64 * m;
-                pre[q][m] = ld_shared(&Lf[(c < nb && r < n) ? (size_t)(k0 + c) * ld + r : (size_t)0]);
+        for (int m = 0; m < MAXM; ++m) {
+            if (k1 + 64 * m < n) {                            // (wave-uniform: slices of 64 rows that exist)
+                const bool in = k1 + lane + 64 * m < n;
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) pre[q][m] = ld_shared(in ? colp[q] + 64 * m : Lf);
             }
         }
 #pragma unroll
@@ -548,6 +560,16 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
     prefetch(nblk - 1);
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * kCB, nb = min(kCB, n - k0), k1 = k0 + nb;
+        unsigned long long tq = prof_now();
+        // x of the rows below the block: one batch of LDS reads (the same rows for every column of the wave), then the
+        // products -- read next to its use, each of them is a round trip of its own
+        double xr[MAXM];
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            const int r = k1 + lane + 64 * m;
+            xr[m] = x_in_lds ? xs[r < n ? r : 0] : gptr(x)[r < n ? r : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < CPW; ++q) {
             const int c = wave + q * NW;
@@ -556,10 +578,9 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
 #pragma unroll
                 for (int m = 0; m < MAXM; ++m) {
                     const int r = k1 + lane + 64 * m;
-                    const double xr = x_in_lds ? xs[r < n ? r : 0] : x[r < n ? r : 0];
-                    if (r < n) acc += pre[q][m] * xr;
+                    if (r < n) acc += pre[q][m] * xr[m];
                 }
-                for (int r = k1 + lane + 64 * MAXM; r < n; r += 64) acc += ld_shared(&Lf[(size_t)(k0 + c) * ld + r]) * x[r];
+                for (int r = k1 + lane + 64 * MAXM; r < n; r += 64) acc += ld_shared(&Lf[(size_t)(k0 + c) * ld + r]) * gptr(x)[r];
                 acc = wave_sum(acc);
                 t[c] = acc;                                   // (uniform: every lane stores it)
             }
@@ -570,8 +591,11 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
             if (idx < kCB * kCB) D[r][c] = (r < nb && c < nb && r >= c) ? dpre[q] : (r == c ? 1.0 : 0.0);
         }
         const double ycur = ypre;
+        prof_add(prof, kProfBsDots, tq); tq = prof_now();
         if (kb > 0) prefetch(kb - 1);
+        prof_add(prof, kProfBsPrefetch, tq); tq = prof_now();
         __syncthreads();
+        prof_add(prof, kProfBsSync, tq); tq = prof_now();
         if (wave == 0) {
             double v = l < nb ? ycur - t[l] : 0.0;
             const double dinv = 1.0 / D[l][l];
@@ -584,11 +608,12 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
                 v = l == r ? xr : (l < r ? fma(-col[r], xr, v) : v);
             }
             if (lane < nb) {
-                x[k0 + lane] = v;
+                gptr(x)[k0 + lane] = v;
                 if (x_in_lds) xs[k0 + lane] = v;
             }
         }
         __syncthreads();
+        prof_add(prof, kProfBsTri, tq);
     }
 }
 
@@ -614,8 +639,9 @@ struct PersistSe2 {
     __device__ static void load_initial(const Dev& D, const double* src, int V, int i)
     {
         const size_t s = (size_t)D.lo + i;
-        D.X.x[i] = src[s]; D.X.y[i] = src[(size_t)V + s]; D.X.th[i] = src[2 * (size_t)V + s];
-        D.X.c[i] = src[3 * (size_t)V + s]; D.X.s[i] = src[4 * (size_t)V + s];
+        auto g = gptr(src);
+        gptr(D.X.x)[i] = g[s]; gptr(D.X.y)[i] = g[(size_t)V + s]; gptr(D.X.th)[i] = g[2 * (size_t)V + s];
+        gptr(D.X.c)[i] = g[3 * (size_t)V + s]; gptr(D.X.s)[i] = g[4 * (size_t)V + s];
     }
     __device__ static void eval(const Dev& D, bool trial, int i, double (&v)[1])
     {
@@ -776,7 +802,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         int info = 0;
         if (alive) info = pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
         prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
-        pchol_backsolve(Lf, n, Dp->rhs, lds);
+        pchol_backsolve(Lf, n, Dp->rhs, lds, P.prof);
         prof_add(P.prof, kProfBacksolve, t0); t0 = prof_now();
         lead_for(nl, [&](int l) { T::nu((*Dp), l); });
         lead_for(L + 2, [&](int j) { T::events((*Dp), j); });
@@ -886,7 +912,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         double mx = 0.0;
         bool nan = false;
         for (int i = tid; i < L + nl; i += kPT) {
-            const double c = Dp->chi_edges[i];
+            const double c = gptr(Dp->chi_edges)[i];
             if (c != c) nan = true; else mx = fmax(mx, c);
         }
         mx = wave_max(mx);

@@ -43,33 +43,48 @@ struct ClusterDev {
 
 __device__ __forceinline__ Pose2 gk_pose(const PoseArr& A, int p)
 {
-    return Pose2{A.x[p], A.y[p], A.th[p], A.c[p], A.s[p]};
+    return Pose2{gptr(A.x)[p], gptr(A.y)[p], gptr(A.th)[p], gptr(A.c)[p], gptr(A.s)[p]};
 }
-__device__ __forceinline__ Sym3 gk_sym(const double* base, int stride, int field0, int idx)
+__device__ __forceinline__ Sym3 gk_sym(const double* base_generic, int stride, int field0, int idx)
 {
-    return load_sym3(base, stride, field0, idx);
+    auto base = gptr(base_generic);
+    Sym3 s;
+    s.a00 = base[(size_t)(field0 + 0) * stride + idx];
+    s.a01 = base[(size_t)(field0 + 1) * stride + idx];
+    s.a02 = base[(size_t)(field0 + 2) * stride + idx];
+    s.a11 = base[(size_t)(field0 + 3) * stride + idx];
+    s.a12 = base[(size_t)(field0 + 4) * stride + idx];
+    s.a22 = base[(size_t)(field0 + 5) * stride + idx];
+    return s;
 }
 
+// GK_OPERANDS_FIRST: the per-index bodies below read all their operands into locals first and put a scheduling barrier
+// behind the reads.  Left alone the scheduler sinks each load next to its use; with hundreds of waves per CU (the
+// one-kernel-per-phase path) that is harmless, but the persistent kernel's leader runs these bodies with two waves per
+// SIMD and then pays one L2 round trip per operand instead of one per body.
 // errors + chi2 of the poses Y (trial or committed); edges 1..L then loops
 __device__ __forceinline__ void gk_eval_at(const ClusterDev& D, const PoseArr& Y, double* eo, double* leo, int i, double (&v)[1])
 {
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(Y, i - 1), b = gk_pose(Y, i);
+        const double tzx = gptr(D.chain)[(size_t)F_TZX * D.estride + k], tzy = gptr(D.chain)[(size_t)F_TZY * D.estride + k];
+        const double cz = gptr(D.chain)[(size_t)F_CZ * D.estride + k], sz = gptr(D.chain)[(size_t)F_SZ * D.estride + k];
+        const double thz = gptr(D.chain)[(size_t)F_THZ * D.estride + k];
+        const Sym3 om = gk_sym(D.chain, D.estride, F_OM, k);
+        __builtin_amdgcn_sched_barrier(0);          // every operand requested before the first is used (see GK_OPERANDS_FIRST)
         double e0, e1, e2;
-        se2_error(a, b, D.chain[(size_t)F_TZX * D.estride + k], D.chain[(size_t)F_TZY * D.estride + k],
-                  D.chain[(size_t)F_CZ * D.estride + k], D.chain[(size_t)F_SZ * D.estride + k],
-                  D.chain[(size_t)F_THZ * D.estride + k], e0, e1, e2);
-        eo[i] = e0; eo[D.ld + i] = e1; eo[2 * D.ld + i] = e2;
-        v[0] = gk_sym(D.chain, D.estride, F_OM, k).quad(e0, e1, e2);
+        se2_error(a, b, tzx, tzy, cz, sz, thz, e0, e1, e2);
+        gptr(eo)[i] = e0; gptr(eo)[D.ld + i] = e1; gptr(eo)[2 * D.ld + i] = e2;
+        v[0] = om.quad(e0, e1, e2);
     } else if (i > D.L && i <= D.L + D.nl) {
-        const int l = i - D.L - 1, c = D.lcand[l];
-        const Pose2 a = gk_pose(Y, D.lfrom[l]), b = gk_pose(Y, D.lto[l]);
+        const int l = i - D.L - 1, c = gptr(D.lcand)[l];
+        const Pose2 a = gk_pose(Y, gptr(D.lfrom)[l]), b = gk_pose(Y, gptr(D.lto)[l]);
         double e0, e1, e2;
-        se2_error(a, b, D.cand[(size_t)F_TZX * D.cstride + c], D.cand[(size_t)F_TZY * D.cstride + c],
-                  D.cand[(size_t)F_CZ * D.cstride + c], D.cand[(size_t)F_SZ * D.cstride + c],
-                  D.cand[(size_t)F_THZ * D.cstride + c], e0, e1, e2);
-        leo[l] = e0; leo[D.nl + l] = e1; leo[2 * D.nl + l] = e2;
+        se2_error(a, b, gptr(D.cand)[(size_t)F_TZX * D.cstride + c], gptr(D.cand)[(size_t)F_TZY * D.cstride + c],
+                  gptr(D.cand)[(size_t)F_CZ * D.cstride + c], gptr(D.cand)[(size_t)F_SZ * D.cstride + c],
+                  gptr(D.cand)[(size_t)F_THZ * D.cstride + c], e0, e1, e2);
+        gptr(leo)[l] = e0; gptr(leo)[D.nl + l] = e1; gptr(leo)[2 * D.nl + l] = e2;
         v[0] = gk_sym(D.cand, D.cstride, F_OM, c).quad(e0, e1, e2);
     }
 }
@@ -86,10 +101,10 @@ __device__ __forceinline__ void gk_chi_edges_at(const ClusterDev& D, int i)
 {
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
-        D.chi_edges[i - 1] = gk_sym(D.chain, D.estride, F_OM, k).quad(D.e[i], D.e[D.ld + i], D.e[2 * D.ld + i]);
+        gptr(D.chi_edges)[i - 1] = gk_sym(D.chain, D.estride, F_OM, k).quad(gptr(D.e)[i], gptr(D.e)[D.ld + i], gptr(D.e)[2 * D.ld + i]);
     } else if (i > D.L && i <= D.L + D.nl) {
         const int l = i - D.L - 1;
-        D.chi_edges[D.L + l] = gk_sym(D.cand, D.cstride, F_OM, D.lcand[l]).quad(D.le[l], D.le[D.nl + l], D.le[2 * D.nl + l]);
+        gptr(D.chi_edges)[D.L + l] = gk_sym(D.cand, D.cstride, F_OM, gptr(D.lcand)[l]).quad(gptr(D.le)[l], gptr(D.le)[D.nl + l], gptr(D.le)[2 * D.nl + l]);
     }
 }
 __global__ void gk_chi_edges(ClusterDev D)
@@ -104,30 +119,33 @@ __device__ __forceinline__ void gk_force_at(const ClusterDev& D, int i)
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
+        const Sym3 om = gk_sym(D.chain, D.estride, F_OM, k);
+        const double e0 = gptr(D.e)[i], e1 = gptr(D.e)[D.ld + i], e2 = gptr(D.e)[2 * D.ld + i];
+        const double cz = gptr(D.chain)[(size_t)F_CZ * D.estride + k], sz = gptr(D.chain)[(size_t)F_SZ * D.estride + k];
+        __builtin_amdgcn_sched_barrier(0);          // every operand requested before the first is used (see GK_OPERANDS_FIRST)
         double q0, q1, q2;
-        gk_sym(D.chain, D.estride, F_OM, k).mul(D.e[i], D.e[D.ld + i], D.e[2 * D.ld + i], q0, q1, q2);
-        const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
+        om.mul(e0, e1, e2, q0, q1, q2);
         const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
         const double gx = cP * q0 - sP * q1, gy = sP * q0 + cP * q1;
         const double dx = b.x - a.x, dy = b.y - a.y;
-        D.g[i] = gx; D.g[D.ld + i] = gy; D.g[2 * D.ld + i] = q2;
-        D.m[i] = gx; D.m[D.ld + i] = gy; D.m[2 * D.ld + i] = q2 + (-dy * gx + dx * gy);
+        gptr(D.g)[i] = gx; gptr(D.g)[D.ld + i] = gy; gptr(D.g)[2 * D.ld + i] = q2;
+        gptr(D.m)[i] = gx; gptr(D.m)[D.ld + i] = gy; gptr(D.m)[2 * D.ld + i] = q2 + (-dy * gx + dx * gy);
     } else if (i > D.L && i <= D.L + D.nl) {
-        const int l = i - D.L - 1, c = D.lcand[l];
-        const Pose2 a = gk_pose(D.X, D.lfrom[l]), b = gk_pose(D.X, D.lto[l]);
+        const int l = i - D.L - 1, c = gptr(D.lcand)[l];
+        const Pose2 a = gk_pose(D.X, gptr(D.lfrom)[l]), b = gk_pose(D.X, gptr(D.lto)[l]);
         double q0, q1, q2;
-        gk_sym(D.cand, D.cstride, F_OM, c).mul(D.le[l], D.le[D.nl + l], D.le[2 * D.nl + l], q0, q1, q2);
-        const double cz = D.cand[(size_t)F_CZ * D.cstride + c], sz = D.cand[(size_t)F_SZ * D.cstride + c];
+        gk_sym(D.cand, D.cstride, F_OM, c).mul(gptr(D.le)[l], gptr(D.le)[D.nl + l], gptr(D.le)[2 * D.nl + l], q0, q1, q2);
+        const double cz = gptr(D.cand)[(size_t)F_CZ * D.cstride + c], sz = gptr(D.cand)[(size_t)F_SZ * D.cstride + c];
         const double cP = a.c * cz - a.s * sz, sP = a.s * cz + a.c * sz;
         const double gx = cP * q0 - sP * q1, gy = sP * q0 + cP * q1;
         const double dx = b.x - a.x, dy = b.y - a.y;
-        D.lg[l] = gx; D.lg[D.nl + l] = gy; D.lg[2 * D.nl + l] = q2;
-        D.lm[l] = gx; D.lm[D.nl + l] = gy; D.lm[2 * D.nl + l] = q2 + (-dy * gx + dx * gy);
+        gptr(D.lg)[l] = gx; gptr(D.lg)[D.nl + l] = gy; gptr(D.lg)[2 * D.nl + l] = q2;
+        gptr(D.lm)[l] = gx; gptr(D.lm)[D.nl + l] = gy; gptr(D.lm)[2 * D.nl + l] = q2 + (-dy * gx + dx * gy);
         // Gamma_l = sigma [[Lam, Lam K],[0,1]],  Lam = R(-(th_f + thz)),  K = J (t_to - o), o = pose 0
         const double A = cP, B = sP;          // cos / sin of (th_f + thz)
-        const double Kx = -(b.y - D.X.y[0]), Ky = b.x - D.X.x[0];
-        const double sg = D.lto[l] > D.lfrom[l] ? 1.0 : -1.0;
-        double* G = D.gam;
+        const double Kx = -(b.y - gptr(D.X.y)[0]), Ky = b.x - gptr(D.X.x)[0];
+        const double sg = gptr(D.lto)[l] > gptr(D.lfrom)[l] ? 1.0 : -1.0;
+        auto G = gptr(D.gam);
         G[0 * D.nl + l] = sg * A;  G[1 * D.nl + l] = sg * B; G[2 * D.nl + l] = sg * (A * Kx + B * Ky);
         G[3 * D.nl + l] = -sg * B; G[4 * D.nl + l] = sg * A; G[5 * D.nl + l] = sg * (-B * Kx + A * Ky);
         G[6 * D.nl + l] = 0.0;     G[7 * D.nl + l] = 0.0;    G[8 * D.nl + l] = sg;
@@ -143,14 +161,14 @@ __global__ void gk_force(ClusterDev D)
 __device__ __forceinline__ void gk_b_at(const ClusterDev& D, int j, double (&v)[1])
 {
     if (j >= 1 && j <= D.L) {
-        double b0 = -D.g[j], b1 = -D.g[D.ld + j], b2 = -D.g[2 * D.ld + j];
-        if (j < D.L) { b0 += D.m[j + 1]; b1 += D.m[D.ld + j + 1]; b2 += D.m[2 * D.ld + j + 1]; }
-        for (int q = D.adj_ptr[j]; q < D.adj_ptr[j + 1]; ++q) {
-            const int it = D.adj_item[q], l = it >> 1;
-            if (it & 1) { b0 -= D.lg[l]; b1 -= D.lg[D.nl + l]; b2 -= D.lg[2 * D.nl + l]; }
-            else        { b0 += D.lm[l]; b1 += D.lm[D.nl + l]; b2 += D.lm[2 * D.nl + l]; }
+        double b0 = -gptr(D.g)[j], b1 = -gptr(D.g)[D.ld + j], b2 = -gptr(D.g)[2 * D.ld + j];
+        if (j < D.L) { b0 += gptr(D.m)[j + 1]; b1 += gptr(D.m)[D.ld + j + 1]; b2 += gptr(D.m)[2 * D.ld + j + 1]; }
+        for (int q = gptr(D.adj_ptr)[j]; q < gptr(D.adj_ptr)[j + 1]; ++q) {
+            const int it = gptr(D.adj_item)[q], l = it >> 1;
+            if (it & 1) { b0 -= gptr(D.lg)[l]; b1 -= gptr(D.lg)[D.nl + l]; b2 -= gptr(D.lg)[2 * D.nl + l]; }
+            else        { b0 += gptr(D.lm)[l]; b1 += gptr(D.lm)[D.nl + l]; b2 += gptr(D.lm)[2 * D.nl + l]; }
         }
-        D.b[j] = b0; D.b[D.ld + j] = b1; D.b[2 * D.ld + j] = b2;
+        gptr(D.b)[j] = b0; gptr(D.b)[D.ld + j] = b1; gptr(D.b)[2 * D.ld + j] = b2;
         v[0] = b0 * b0 + b1 * b1 + b2 * b2;
     }
 }
@@ -168,15 +186,21 @@ __device__ __forceinline__ void gk_bHb_psi_at(const ClusterDev& D, int i, double
     if (i >= 1 && i <= D.L) {
         const int k = D.lo + i - 1;
         const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
-        const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
-        const double va0 = i > 1 ? D.b[i - 1] : 0.0, va1 = i > 1 ? D.b[D.ld + i - 1] : 0.0, va2 = i > 1 ? D.b[2 * D.ld + i - 1] : 0.0;
+        const double cz = gptr(D.chain)[(size_t)F_CZ * D.estride + k], sz = gptr(D.chain)[(size_t)F_SZ * D.estride + k];
+        const int ia = i > 1 ? i - 1 : i;               // (row 0 of b carries nothing: read a valid slot, select afterwards)
+        const double ra0 = gptr(D.b)[ia], ra1 = gptr(D.b)[D.ld + ia], ra2 = gptr(D.b)[2 * D.ld + ia];
+        const double vb0 = gptr(D.b)[i], vb1 = gptr(D.b)[D.ld + i], vb2 = gptr(D.b)[2 * D.ld + i];
+        const Sym3 om = gk_sym(D.chain, D.estride, F_OM, k), sg = gk_sym(D.chain, D.estride, F_SG, k);
+        const double ox = gptr(D.X.x)[0], oy = gptr(D.X.y)[0];
+        const double ee0 = gptr(D.e)[i], ee1 = gptr(D.e)[D.ld + i], ee2 = gptr(D.e)[2 * D.ld + i];
+        __builtin_amdgcn_sched_barrier(0);          // every operand requested before the first is used (see GK_OPERANDS_FIRST)
+        const double va0 = i > 1 ? ra0 : 0.0, va1 = i > 1 ? ra1 : 0.0, va2 = i > 1 ? ra2 : 0.0;
         double wx, wy, wth;
-        se2_apply_J(a, b, cz, sz, va0, va1, va2, D.b[i], D.b[D.ld + i], D.b[2 * D.ld + i], wx, wy, wth);
-        v[0] = gk_sym(D.chain, D.estride, F_OM, k).quad(wx, wy, wth);
+        se2_apply_J(a, b, cz, sz, va0, va1, va2, vb0, vb1, vb2, wx, wy, wth);
+        v[0] = om.quad(wx, wy, wth);
         // Psi_j = Phi Cov Phi^T, w_j = Phi e_j,  Phi = [[P, -kappa],[0,1]], kappa = J (t_j - o)
-        const Sym3 sg = gk_sym(D.chain, D.estride, F_SG, k);
         const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
-        const double kx = -(b.y - D.X.y[0]), ky = b.x - D.X.x[0];
+        const double kx = -(b.y - oy), ky = b.x - ox;
         const double cc = c * c, ss = sn * sn, cs = c * sn;
         const double C00 = cc * sg.a00 - 2 * cs * sg.a01 + ss * sg.a11;
         const double C01 = cs * (sg.a00 - sg.a11) + (cc - ss) * sg.a01;
@@ -184,29 +208,28 @@ __device__ __forceinline__ void gk_bHb_psi_at(const ClusterDev& D, int i, double
         const double c0 = c * sg.a02 - sn * sg.a12, c1 = sn * sg.a02 + c * sg.a12;
         const double sth = sg.a22;
         const double p02 = c0 - sth * kx, p12 = c1 - sth * ky;
-        D.ps[0 * D.ld + i] = C00 - kx * c0 - kx * p02;
-        D.ps[1 * D.ld + i] = C01 - kx * c1 - ky * p02;
-        D.ps[2 * D.ld + i] = p02;
-        D.ps[3 * D.ld + i] = C11 - ky * c1 - ky * p12;
-        D.ps[4 * D.ld + i] = p12;
-        D.ps[5 * D.ld + i] = sth;
-        const double e0 = D.e[i], e1 = D.e[D.ld + i], e2 = D.e[2 * D.ld + i];
-        D.ps[6 * D.ld + i] = c * e0 - sn * e1 - kx * e2;
-        D.ps[7 * D.ld + i] = sn * e0 + c * e1 - ky * e2;
-        D.ps[8 * D.ld + i] = e2;
+        gptr(D.ps)[0 * D.ld + i] = C00 - kx * c0 - kx * p02;
+        gptr(D.ps)[1 * D.ld + i] = C01 - kx * c1 - ky * p02;
+        gptr(D.ps)[2 * D.ld + i] = p02;
+        gptr(D.ps)[3 * D.ld + i] = C11 - ky * c1 - ky * p12;
+        gptr(D.ps)[4 * D.ld + i] = p12;
+        gptr(D.ps)[5 * D.ld + i] = sth;
+        gptr(D.ps)[6 * D.ld + i] = c * ee0 - sn * ee1 - kx * ee2;
+        gptr(D.ps)[7 * D.ld + i] = sn * ee0 + c * ee1 - ky * ee2;
+        gptr(D.ps)[8 * D.ld + i] = ee2;
     } else if (i > D.L && i <= D.L + D.nl) {
-        const int l = i - D.L - 1, c = D.lcand[l];
-        const int f = D.lfrom[l], t = D.lto[l];
+        const int l = i - D.L - 1, c = gptr(D.lcand)[l];
+        const int f = gptr(D.lfrom)[l], t = gptr(D.lto)[l];
         const Pose2 a = gk_pose(D.X, f), b = gk_pose(D.X, t);
-        const double va0 = f > 0 ? D.b[f] : 0.0, va1 = f > 0 ? D.b[D.ld + f] : 0.0, va2 = f > 0 ? D.b[2 * D.ld + f] : 0.0;
-        const double vb0 = t > 0 ? D.b[t] : 0.0, vb1 = t > 0 ? D.b[D.ld + t] : 0.0, vb2 = t > 0 ? D.b[2 * D.ld + t] : 0.0;
+        const double va0 = f > 0 ? gptr(D.b)[f] : 0.0, va1 = f > 0 ? gptr(D.b)[D.ld + f] : 0.0, va2 = f > 0 ? gptr(D.b)[2 * D.ld + f] : 0.0;
+        const double vb0 = t > 0 ? gptr(D.b)[t] : 0.0, vb1 = t > 0 ? gptr(D.b)[D.ld + t] : 0.0, vb2 = t > 0 ? gptr(D.b)[2 * D.ld + t] : 0.0;
         double wx, wy, wth;
-        se2_apply_J(a, b, D.cand[(size_t)F_CZ * D.cstride + c], D.cand[(size_t)F_SZ * D.cstride + c], va0, va1, va2,
+        se2_apply_J(a, b, gptr(D.cand)[(size_t)F_CZ * D.cstride + c], gptr(D.cand)[(size_t)F_SZ * D.cstride + c], va0, va1, va2,
                     vb0, vb1, vb2, wx, wy, wth);
         v[0] = gk_sym(D.cand, D.cstride, F_OM, c).quad(wx, wy, wth);
     } else if (i == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) D.ps[k * D.ld] = 0.0;
+        for (int k = 0; k < 9; ++k) gptr(D.ps)[k * D.ld] = 0.0;
     }
 }
 __global__ void gk_bHb_psi(ClusterDev D)
@@ -222,26 +245,26 @@ __device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int 
 {
     if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
     const int NS = 3 * D.nl;
-    const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
-    const int lo2 = min(D.lfrom[l2], D.lto[l2]), hi2 = max(D.lfrom[l2], D.lto[l2]);
+    const int lo1 = min(gptr(D.lfrom)[l1], gptr(D.lto)[l1]), hi1 = max(gptr(D.lfrom)[l1], gptr(D.lto)[l1]);
+    const int lo2 = min(gptr(D.lfrom)[l2], gptr(D.lto)[l2]), hi2 = max(gptr(D.lfrom)[l2], gptr(D.lto)[l2]);
     const int a = max(lo1, lo2), bq = min(hi1, hi2);
     double Mm[6] = {0, 0, 0, 0, 0, 0};
     if (bq > a) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Mm[k] = D.ps[k * D.ld + bq] - D.ps[k * D.ld + a];
+        for (int k = 0; k < 6; ++k) Mm[k] = gptr(D.ps)[k * D.ld + bq] - gptr(D.ps)[k * D.ld + a];
     }
     double G1[3][3], G2[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { G1[r][c] = D.gam[(3 * r + c) * D.nl + l1]; G2[r][c] = D.gam[(3 * r + c) * D.nl + l2]; }
+        for (int c = 0; c < 3; ++c) { G1[r][c] = gptr(D.gam)[(3 * r + c) * D.nl + l1]; G2[r][c] = gptr(D.gam)[(3 * r + c) * D.nl + l2]; }
     const double M3[3][3] = {{Mm[0], Mm[1], Mm[2]}, {Mm[1], Mm[3], Mm[4]}, {Mm[2], Mm[4], Mm[5]}};
     double GM[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) GM[r][c] = G1[r][0] * M3[0][c] + G1[r][1] * M3[1][c] + G1[r][2] * M3[2][c];
-    const Sym3 sgl = gk_sym(D.cand, D.cstride, F_SG, D.lcand[l1]);
+    const Sym3 sgl = gk_sym(D.cand, D.cstride, F_SG, gptr(D.lcand)[l1]);
     const double Sg[3][3] = {{sgl.a00, sgl.a01, sgl.a02}, {sgl.a01, sgl.a11, sgl.a12}, {sgl.a02, sgl.a12, sgl.a22}};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -252,12 +275,12 @@ __device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int 
             st_shared(&D.S[(size_t)(3 * l2 + c) * D.ldS + (3 * l1 + r)], t);
         }
     if (l1 == l2) {
-        const double W0 = D.ps[6 * D.ld + hi1] - D.ps[6 * D.ld + lo1];
-        const double W1 = D.ps[7 * D.ld + hi1] - D.ps[7 * D.ld + lo1];
-        const double W2 = D.ps[8 * D.ld + hi1] - D.ps[8 * D.ld + lo1];
+        const double W0 = gptr(D.ps)[6 * D.ld + hi1] - gptr(D.ps)[6 * D.ld + lo1];
+        const double W1 = gptr(D.ps)[7 * D.ld + hi1] - gptr(D.ps)[7 * D.ld + lo1];
+        const double W2 = gptr(D.ps)[8 * D.ld + hi1] - gptr(D.ps)[8 * D.ld + lo1];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            st_shared(&D.S[(size_t)(3 * l1 + r) * D.ldS + NS], D.le[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2));
+            st_shared(&D.S[(size_t)(3 * l1 + r) * D.ldS + NS], gptr(D.le)[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2));
     }
 }
 __global__ void gk_assemble(ClusterDev D)
@@ -273,8 +296,8 @@ __device__ __forceinline__ void gk_nu_at(const ClusterDev& D, int l)
     for (int c = 0; c < 3; ++c) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) t += D.gam[(3 * r + c) * D.nl + l] * D.rhs[3 * l + r];
-        D.nu[c * D.nl + l] = t;
+        for (int r = 0; r < 3; ++r) t += gptr(D.gam)[(3 * r + c) * D.nl + l] * gptr(D.rhs)[3 * l + r];
+        gptr(D.nu)[c * D.nl + l] = t;
     }
 }
 __global__ void gk_nu(ClusterDev D)
@@ -289,13 +312,13 @@ __device__ __forceinline__ void gk_events_at(const ClusterDev& D, int j)
     if (j > D.L + 1) return;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (j >= 1) {
-        for (int q = D.ev_ptr[j]; q < D.ev_ptr[j + 1]; ++q) {
-            const int it = D.ev_item[q], l = it >> 1;
+        for (int q = gptr(D.ev_ptr)[j]; q < gptr(D.ev_ptr)[j + 1]; ++q) {
+            const int it = gptr(D.ev_item)[q], l = it >> 1;
             const double sgn = (it & 1) ? -1.0 : 1.0;
-            a0 += sgn * D.nu[l]; a1 += sgn * D.nu[D.nl + l]; a2 += sgn * D.nu[2 * D.nl + l];
+            a0 += sgn * gptr(D.nu)[l]; a1 += sgn * gptr(D.nu)[D.nl + l]; a2 += sgn * gptr(D.nu)[2 * D.nl + l];
         }
     }
-    D.nd[j] = a0; D.nd[D.ld + j] = a1; D.nd[2 * D.ld + j] = a2;
+    gptr(D.nd)[j] = a0; gptr(D.nd)[D.ld + j] = a1; gptr(D.nd)[2 * D.ld + j] = a2;
 }
 __global__ void gk_events(ClusterDev D)
 {
@@ -309,17 +332,21 @@ __device__ __forceinline__ void gk_rho_at(const ClusterDev& D, int i)
     if (i < 1 || i > D.L) return;
     const int k = D.lo + i - 1;
     const Pose2 a = gk_pose(D.X, i - 1), b = gk_pose(D.X, i);
-    const double cz = D.chain[(size_t)F_CZ * D.estride + k], sz = D.chain[(size_t)F_SZ * D.estride + k];
+    const double cz = gptr(D.chain)[(size_t)F_CZ * D.estride + k], sz = gptr(D.chain)[(size_t)F_SZ * D.estride + k];
+    const double ox = gptr(D.X.x)[0], oy = gptr(D.X.y)[0];
+    const double n0 = gptr(D.nd)[i], n1 = gptr(D.nd)[D.ld + i], n2 = gptr(D.nd)[2 * D.ld + i];
+    const Sym3 sg = gk_sym(D.chain, D.estride, F_SG, k);
+    const double e0 = gptr(D.e)[i], e1 = gptr(D.e)[D.ld + i], e2 = gptr(D.e)[2 * D.ld + i];
+    __builtin_amdgcn_sched_barrier(0);              // GK_OPERANDS_FIRST
     const double c = a.c * cz - a.s * sz, sn = a.s * cz + a.c * sz;
-    const double kx = -(b.y - D.X.y[0]), ky = b.x - D.X.x[0];
-    const double n0 = D.nd[i], n1 = D.nd[D.ld + i], n2 = D.nd[2 * D.ld + i];
+    const double kx = -(b.y - oy), ky = b.x - ox;
     const double wx = c * n0 + sn * n1, wy = -sn * n0 + c * n1, wth = -(kx * n0 + ky * n1) + n2;
     double vx, vy, vth;
-    gk_sym(D.chain, D.estride, F_SG, k).mul(wx, wy, wth, vx, vy, vth);
-    const double ux = -vx - D.e[i], uy = -vy - D.e[D.ld + i], uth = -vth - D.e[2 * D.ld + i];
-    D.sc[i] = uth;
-    D.sc[D.ld + i] = c * ux - sn * uy;
-    D.sc[2 * D.ld + i] = sn * ux + c * uy;
+    sg.mul(wx, wy, wth, vx, vy, vth);
+    const double ux = -vx - e0, uy = -vy - e1, uth = -vth - e2;
+    gptr(D.sc)[i] = uth;
+    gptr(D.sc)[D.ld + i] = c * ux - sn * uy;
+    gptr(D.sc)[2 * D.ld + i] = sn * ux + c * uy;
 }
 __global__ void gk_rho(ClusterDev D)
 {
@@ -330,10 +357,10 @@ __global__ void gk_rho(ClusterDev D)
 __device__ __forceinline__ void gk_term_at(const ClusterDev& D, int i)
 {
     if (i < 1 || i > D.L) return;
-    const double thPrev = i > 1 ? D.sc[i - 1] : 0.0;
-    const double dx = D.X.x[i] - D.X.x[i - 1], dy = D.X.y[i] - D.X.y[i - 1];
-    D.sc[D.ld + i] += -dy * thPrev;
-    D.sc[2 * D.ld + i] += dx * thPrev;
+    const double thPrev = i > 1 ? gptr(D.sc)[i - 1] : 0.0;
+    const double dx = gptr(D.X.x)[i] - gptr(D.X.x)[i - 1], dy = gptr(D.X.y)[i] - gptr(D.X.y)[i - 1];
+    gptr(D.sc)[D.ld + i] += -dy * thPrev;
+    gptr(D.sc)[2 * D.ld + i] += dx * thPrev;
 }
 __global__ void gk_term(ClusterDev D)
 {
@@ -344,10 +371,10 @@ __global__ void gk_term(ClusterDev D)
 __device__ __forceinline__ void gk_h_at(const ClusterDev& D, int i, double (&v)[2])
 {
     if (i >= 1 && i <= D.L) {
-        const double h0 = D.sc[D.ld + i], h1 = D.sc[2 * D.ld + i], h2 = D.sc[i];
-        D.h[i] = h0; D.h[D.ld + i] = h1; D.h[2 * D.ld + i] = h2;
+        const double h0 = gptr(D.sc)[D.ld + i], h1 = gptr(D.sc)[2 * D.ld + i], h2 = gptr(D.sc)[i];
+        gptr(D.h)[i] = h0; gptr(D.h)[D.ld + i] = h1; gptr(D.h)[2 * D.ld + i] = h2;
         v[0] = h0 * h0 + h1 * h1 + h2 * h2;
-        v[1] = D.b[i] * h0 + D.b[D.ld + i] * h1 + D.b[2 * D.ld + i] * h2;
+        v[1] = gptr(D.b)[i] * h0 + gptr(D.b)[D.ld + i] * h1 + gptr(D.b)[2 * D.ld + i] * h2;
     }
 }
 __global__ void gk_h(ClusterDev D)
@@ -363,7 +390,7 @@ __device__ __forceinline__ void gk_blend_at(const ClusterDev& D, double alpha, i
     if (i >= 1 && i <= D.L) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double sk = alpha * D.b[k * D.ld + i], ak = D.h[k * D.ld + i] - sk;
+            const double sk = alpha * gptr(D.b)[k * D.ld + i], ak = gptr(D.h)[k * D.ld + i] - sk;
             v[0] += sk * ak;
             v[1] += ak * ak;
         }
@@ -379,15 +406,19 @@ __global__ void gk_blend(ClusterDev D, double alpha)
 // trial poses Xn = X (+) (p b + q h); partial "changed" count
 __device__ __forceinline__ void gk_update_at(const ClusterDev& D, double p, double q, int i, double (&v)[1])
 {
-    if (i == 0) { D.Xn.x[0] = D.X.x[0]; D.Xn.y[0] = D.X.y[0]; D.Xn.th[0] = D.X.th[0]; D.Xn.c[0] = D.X.c[0]; D.Xn.s[0] = D.X.s[0]; }
+    if (i == 0) { gptr(D.Xn.x)[0] = gptr(D.X.x)[0]; gptr(D.Xn.y)[0] = gptr(D.X.y)[0]; gptr(D.Xn.th)[0] = gptr(D.X.th)[0]; gptr(D.Xn.c)[0] = gptr(D.X.c)[0]; gptr(D.Xn.s)[0] = gptr(D.X.s)[0]; }
     if (i >= 1 && i <= D.L) {
-        const double x = D.X.x[i] + fma(p, D.b[i], q * D.h[i]);
-        const double y = D.X.y[i] + fma(p, D.b[D.ld + i], q * D.h[D.ld + i]);
-        const double th = wrap_pi(D.X.th[i] + fma(p, D.b[2 * D.ld + i], q * D.h[2 * D.ld + i]));
+        const double x0 = gptr(D.X.x)[i], y0 = gptr(D.X.y)[i], th0 = gptr(D.X.th)[i];
+        const double b0 = gptr(D.b)[i], b1 = gptr(D.b)[D.ld + i], b2 = gptr(D.b)[2 * D.ld + i];
+        const double h0 = gptr(D.h)[i], h1 = gptr(D.h)[D.ld + i], h2 = gptr(D.h)[2 * D.ld + i];
+        __builtin_amdgcn_sched_barrier(0);              // GK_OPERANDS_FIRST
+        const double x = x0 + fma(p, b0, q * h0);
+        const double y = y0 + fma(p, b1, q * h1);
+        const double th = wrap_pi(th0 + fma(p, b2, q * h2));
         double s, c;
         sincos_pi(th, s, c);
-        D.Xn.x[i] = x; D.Xn.y[i] = y; D.Xn.th[i] = th; D.Xn.c[i] = c; D.Xn.s[i] = s;
-        v[0] = (x != D.X.x[i] || y != D.X.y[i] || th != D.X.th[i]) ? 1.0 : 0.0;
+        gptr(D.Xn.x)[i] = x; gptr(D.Xn.y)[i] = y; gptr(D.Xn.th)[i] = th; gptr(D.Xn.c)[i] = c; gptr(D.Xn.s)[i] = s;
+        v[0] = (x != x0 || y != y0 || th != th0) ? 1.0 : 0.0;
     }
 }
 __global__ void gk_update(ClusterDev D, double p, double q)

@@ -780,7 +780,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         hipMemcpy(p, h->d_prof, sizeof(p), hipMemcpyDeviceToHost);
         static const char* names[kProfN] = {"total", "pre", "handoff", "assemble", "factor", "factor_work", "factor_wait", "backsolve",
                                             "post", "trial", "rest", "iterations", "steps", "help_dt", "help_solve", "help_update", "help_wait",
-                                            "look_load", "look_solve", "look_fill", "look_potrf", "look_publish"};
+                                            "look_load", "look_solve", "look_fill", "look_potrf", "look_publish", "bs_dots", "bs_prefetch", "bs_sync", "bs_triangle"};
         fprintf(stderr, "{\"persist_profile_us\": {");
         for (int k = 0; k < kProfN; ++k)
             fprintf(stderr, "%s\"%s\": %.1f", k ? ", " : "", names[k], (k == kProfIterations || k == kProfSteps) ? (double)p[k] : p[k] * 0.01);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kPT, 1) void k_trsm(const double* src, int reps, un
             double x[kCB];
 #pragma unroll
             for (int c = 0; c < kCB; ++c) x[c] = src[c * 64 + lane] + r;
-            trsm32(x, DT, [&](int p, double v) { P[p][lane] = v; });
+            trsm32<false>(x, DT, [&](int p, double v) { P[p][lane] = v; });
         }
         __syncthreads();
         tot += wall_clock64() - t0;
