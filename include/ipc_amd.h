@@ -136,6 +136,9 @@ typedef struct {
     int damped_cells;        /* cells whose linear solve met a non-positive pivot and were solved again with g2o's
                                 Levenberg retry (lambda 1e-7 x 10 per failure up to 1e3, sticky for the rest of the
                                 optimisation) on the literal normal equations                                      */
+    int literal_cells;       /* cells whose max chi2 ended within IPC_BORDERLINE_BAND (default 4 sqrt(IPC_TERMINATE_EPS),
+                                relative) of their threshold and were solved again by g2o's literal trial loop, so the
+                                convergence test cannot have changed their decision                                 */
 } ipc_solve_report_t;
 int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out);
 

@@ -48,7 +48,7 @@ class CheckInfo(C.Structure):
 
 class SolveReport(C.Structure):
     _fields_ = [("cells", C.c_int), ("long_cells", C.c_int), ("failed_cells", C.c_int), ("capped_cells", C.c_int),
-                ("nan_cells", C.c_int), ("damped_cells", C.c_int)]
+                ("nan_cells", C.c_int), ("damped_cells", C.c_int), ("literal_cells", C.c_int)]
 
 
 CELL_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("max_chi2", "<f8"),

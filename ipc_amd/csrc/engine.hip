@@ -559,6 +559,11 @@ struct ipc_engine {
     int* d_slot = nullptr; int slot_world = 0; int row_policy = 1;    // row -> shard slot of the last world size (IPC_ROW_BALANCE=cyclic|cost)
     int* d_failed = nullptr; int last_lm_cells = 0;    // cells of the last solve redone with Levenberg damping
     bool lm_retry = true;                              // IPC_LM_RETRY=0: a failed linear solve ends the optimisation (flags & 2), no damping
+    // Cells whose max chi2 ends within this relative distance of their threshold are solved again with g2o's literal
+    // trial loop (term_eps 0): the convergence test can move an edge's chi2 by up to 2 sqrt(term_eps) relative,
+    // so outside the band the decision of the literal loop is the one already taken.  IPC_BORDERLINE_BAND (0: off).
+    double borderline_band = -1.0;                     // < 0: 4 sqrt(term_eps)
+    int last_literal_cells = 0;
     long lm_fallbacks = 0;
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
@@ -661,7 +666,12 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         if (!make_plan(h->plan, dim, perr)) { delete h; return fail(IPC_ERR_ARG, "%s", perr.c_str()); }
     }
     if (const char* te = getenv("IPC_TERMINATE_EPS")) {
-        if (*te) h->term_eps = atof(te);
+        if (*te) {
+            char* end = nullptr;
+            h->term_eps = strtod(te, &end);                          // "1e-13x", "off": refused, not read as 0
+            while (end && (*end == ' ' || *end == '\t')) ++end;
+            if (end == te || (end && *end)) { delete h; return fail(IPC_ERR_ARG, "IPC_TERMINATE_EPS: '%s' is not a number", te); }
+        }
         if (!(h->term_eps >= 0) || h->term_eps > 1e-6) { delete h; return fail(IPC_ERR_ARG, "IPC_TERMINATE_EPS must be in [0, 1e-6]"); }
     }
     if (const char* pp = getenv("IPC_PERSIST_PROF")) {
@@ -672,6 +682,16 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
     if (const char* lm = getenv("IPC_LM_RETRY")) { if (*lm) h->lm_retry = atoi(lm) != 0; }
+    if (const char* bb = getenv("IPC_BORDERLINE_BAND")) {
+        if (*bb) {
+            char* end = nullptr;
+            h->borderline_band = strtod(bb, &end);
+            if (end == bb || *end || !(h->borderline_band >= 0) || h->borderline_band > 0.5) {
+                delete h;
+                return fail(IPC_ERR_ARG, "IPC_BORDERLINE_BAND must be a number in [0, 0.5]");
+            }
+        }
+    }
     if (const char* rb = getenv("IPC_ROW_BALANCE")) {
         if (!strcmp(rb, "cyclic")) h->row_policy = 0;
         else if (*rb && strcmp(rb, "cost")) { delete h; return fail(IPC_ERR_ARG, "IPC_ROW_BALANCE must be 'cost' or 'cyclic'"); }
@@ -1060,31 +1080,51 @@ static int ensure_row_map(ipc_engine* h, int world)
 // Cells whose capacitance factorisation met a non-positive pivot (flags & 2: degenerate information matrices, NaN
 // poses): g2o retries such a solve with Levenberg damping.  The cell kernels cannot (see cluster_common.hpp), so the
 // few cells concerned are solved again by the host-driven cluster solver, which can -- same check, open-loop start.
-__global__ void k_collect_failed(int ncells, const int4* meta, int cap, int* list, int* count)
+// Borderline cells (see ipc_engine::borderline_band) are collected by the same pass, listed as ~c.
+__global__ void k_collect_failed(int ncells, const int4* meta, const double* chi, const int2* cells, double fast_th,
+                                 double slow_th, double band, bool want_failed, int cap, int* list, int* count)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells || !(meta[c].z & 2)) return;
+    if (c >= ncells) return;
+    const bool failed = want_failed && (meta[c].z & 2);
+    bool border = false;
+    if (!failed && band > 0.0) {
+        const int2 cc = cells[c];
+        const double th = cc.x == cc.y ? fast_th : slow_th;
+        border = fabs(chi[c] - th) <= band * th;                     // (NaN: no)
+    }
+    if (!failed && !border) return;
     const int q = atomicAdd(count, 1);
-    if (q < cap) list[q] = c;
+    if (q < cap) list[q] = failed ? c : ~c;
 }
 static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
 {
     constexpr int kCap = 16384;
     if (!h->d_failed) HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * (kCap + 1)));
     HIPCHK(hipMemsetAsync(h->d_failed + kCap, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_collect_failed, dim3((total + 255) / 256), dim3(256), 0, st, total, (const int4*)h->d_meta, kCap,
-                       h->d_failed, h->d_failed + kCap);
+    const double band = h->term_eps > 0 ? (h->borderline_band >= 0 ? h->borderline_band : 4.0 * std::sqrt(h->term_eps)) : 0.0;
+    hipLaunchKernelGGL(k_collect_failed, dim3((total + 255) / 256), dim3(256), 0, st, total, (const int4*)h->d_meta,
+                       (const double*)h->d_chi, (const int2*)h->d_cells, h->prm.fast_reject_th, h->prm.slow_reject_th, band,
+                       h->lm_retry, kCap, h->d_failed, h->d_failed + kCap);
     int n = 0;
     HIPCHK(hipMemcpyAsync(&n, h->d_failed + kCap, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->last_lm_cells = 0;
+    h->last_literal_cells = 0;
     if (n == 0) return IPC_OK;
     n = std::min(n, kCap);
     if (int rc = ensure_incremental(h, "ipc_solve_rows")) return rc;
     std::vector<int> idx(n);
     HIPCHK(hipMemcpy(idx.data(), h->d_failed, sizeof(int) * n, hipMemcpyDeviceToHost));
-    std::sort(idx.begin(), idx.end());
+    std::sort(idx.begin(), idx.end(), [](int a, int b) { return (a < 0 ? ~a : a) < (b < 0 ? ~b : b); });
+    auto set_eps = [&](double eps) {
+        if (h->dim == 3) { h->cluster3->term_eps = eps; if (h->persist3) h->persist3->term_eps = eps; }
+        else { h->cluster->term_eps = eps; if (h->persist2) h->persist2->term_eps = eps; }
+    };
     for (int q = 0; q < n; ++q) {
+        const bool literal = idx[q] < 0;                             // borderline: the same check by g2o's literal loop
+        if (literal) idx[q] = ~idx[q];
+        set_eps(literal ? 0.0 : h->term_eps);
         int2 cell;
         HIPCHK(hipMemcpy(&cell, h->d_cells + idx[q], sizeof(int2), hipMemcpyDeviceToHost));
         const int i = cell.x, j = cell.y, nl = i == j ? 1 : 2;
@@ -1094,13 +1134,15 @@ static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
         int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
         if ((hi - lo) + nl > 100) iters *= 5;                                  // consensus_utils.cpp:12-13
         ClusterOut o;
-        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, true));
+        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, !literal));    // (damping: host-driven solver)
         const int4 meta = make_int4(o.iterations, o.tries, o.flags, o.evals);
         HIPCHK(hipMemcpy(h->d_chi + idx[q], &o.max_chi2, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_chitot + idx[q], &o.chi2_total, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_meta + idx[q], &meta, sizeof(int4), hipMemcpyHostToDevice));
-        ++h->last_lm_cells;
+        if (literal) ++h->last_literal_cells;
+        else ++h->last_lm_cells;
     }
+    set_eps(h->term_eps);
     return IPC_OK;
 }
 
@@ -1230,7 +1272,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     h->last_launches = launches;
     h->last_cells = (int)total;
     h->last_long_cells = (int)n_long;
-    if (total && h->lm_retry) {
+    if (total && (h->lm_retry || (h->term_eps > 0 && h->borderline_band != 0.0))) {
         if (int rc = resolve_failed_cells(h, st, (int)total)) return rc;
     }
     if (total)
@@ -1363,6 +1405,7 @@ extern "C" int ipc_solve_report(ipc_engine_t* h, ipc_solve_report_t* out)
     out->capped_cells = (int)host[1];
     out->nan_cells = (int)host[2];
     out->damped_cells = h->last_lm_cells;
+    out->literal_cells = h->last_literal_cells;
     return IPC_OK;
 }
 

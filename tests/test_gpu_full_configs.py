@@ -216,3 +216,39 @@ def test_convergence_test_against_the_literal_g2o_loop(name, monkeypatch):
     rel = np.abs(a[2]["max_chi2"] - b[2]["max_chi2"]) / np.maximum(np.abs(a[2]["max_chi2"]), 1e-300)
     assert float(rel.max()) <= 1e-6
     assert b[2]["evals"].sum() < 0.8 * a[2]["evals"].sum()        # the test does remove residual passes
+
+
+def test_borderline_cells_are_solved_again_by_the_literal_loop(monkeypatch):
+    """A cell whose max chi2 ends within IPC_BORDERLINE_BAND (default 4 sqrt(IPC_TERMINATE_EPS), relative) of its
+    threshold is solved again with the convergence test off, so the test cannot have changed a decision.  With the band
+    opened to 5 % the pass has cells to work on (C1): they are reported, carry the literal loop's chi2 (to 1e-6: two solvers, and
+    the trial sequence that ends g2o's loop is rounding-driven) and nothing else of the matrix moves; a malformed IPC_TERMINATE_EPS is refused, not read as 0."""
+    from bench import build_workload
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = build_workload("C1")
+    res = {}
+    for mode, env in (("literal", {"IPC_TERMINATE_EPS": "0"}), ("default", {}), ("wide", {"IPC_BORDERLINE_BAND": "0.05"}),
+                      ("off", {"IPC_BORDERLINE_BAND": "0"})):
+        for k in ("IPC_TERMINATE_EPS", "IPC_BORDERLINE_BAND"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = IPC(g, cfg, device=0)
+        bits, acc = eng.run()
+        c = eng.cell_info()
+        res[mode] = (bits.copy(), acc.copy(), c[np.lexsort((c["j"], c["i"]))], eng.solve_report())
+        eng.close()
+    lit, wide, off, dflt = res["literal"], res["wide"], res["off"], res["default"]
+    assert lit[3]["literal_cells"] == 0 and off[3]["literal_cells"] == 0
+    th = np.where(wide[2]["i"] == wide[2]["j"], cfg.fast_reject_th, cfg.slow_reject_th)
+    near = np.abs(off[2]["max_chi2"] - th) <= 0.05 * th
+    assert wide[3]["literal_cells"] == int(near.sum()) > 0, (wide[3], int(near.sum()))
+    assert dflt[3]["literal_cells"] <= 2                          # a 1.3e-6 band: a cell or two of 50 000 at most
+    for r in (wide, off, dflt):
+        assert np.array_equal(r[0], lit[0]) and np.array_equal(r[1], lit[1])
+    rel = np.abs(wide[2]["max_chi2"] - lit[2]["max_chi2"]) / np.maximum(np.abs(lit[2]["max_chi2"]), 1e-300)
+    assert float(rel[near].max()) <= 1e-6, float(rel[near].max())
+    assert np.array_equal(wide[2]["max_chi2"][~near], off[2]["max_chi2"][~near])
+    monkeypatch.setenv("IPC_TERMINATE_EPS", "1e-13x")
+    with pytest.raises(Exception, match="IPC_TERMINATE_EPS"):
+        IPC(g, cfg, device=0)
