@@ -1000,6 +1000,11 @@ public:
     hipError_t wait(ClusterOut& out)
     {
         IPC_CL_CHK(hipStreamSynchronize(st_));
+        return fetch(out);
+    }
+    // the result record of a solve known to have ended (an event behind launch() has completed)
+    hipError_t fetch(ClusterOut& out)
+    {
         out = ClusterOut{};
         out.max_chi2 = h_out_->max_chi2; out.chi2_total = h_out_->chi2_total; out.chi2_initial = h_out_->chi2_initial;
         out.iterations = h_out_->iterations; out.tries = h_out_->tries; out.flags = h_out_->flags; out.evals = h_out_->evals;

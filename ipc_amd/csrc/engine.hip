@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -569,31 +570,60 @@ struct ipc_engine {
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
     int max_helpers = -1;                              // IPC_PERSIST_HELPERS
-    // Speculative candidate window of the faithful mode (IPC_SPEC_WINDOW, default 8; 1 = off).  A rejected candidate
-    // leaves the state untouched (reference src/consensus.cpp:63-67), so the checks of the candidates that FOLLOW in
-    // the processing order can start from the same state before its verdict is known: up to `spec_window` cluster
-    // solves run concurrently, each in its own persistent launch on its own stream.  A result is only ever used if
-    // no commit happened since its launch (state_version); on an accept the others are told to stop and are redone.
+    // Speculative candidate pipeline of the faithful mode (IPC_SPEC_WINDOW solves in flight, default 8; 1 = off).
+    // A rejected candidate leaves the state untouched (reference src/consensus.cpp:63-67), so the checks of the candidates
+    // that FOLLOW in the processing order can start from the same state before its verdict is known; and the state an
+    // accept leaves behind is known as soon as ITS solve ends, so the candidates after it start from that state while
+    // slower, earlier solves are still running (assumed to reject -- 87 % do on C2).  Solves run in persistent launches
+    // on their own streams; finished results are parked on the host until their candidate is asked for.  A result is
+    // used only if the state it started from is, at that moment, the committed one: every decision is the one the
+    // one-at-a-time loop takes.  An accept nobody assumed tells the later solves to stop (host-mapped word) and they are
+    // redone from the new state.
     struct SpecSlot {
         PersistSolver<PersistSe2>* s2 = nullptr;
         PersistSolver<PersistSe3>* s3 = nullptr;
         hipStream_t st = nullptr;
-        int cand = -1;                                 // candidate whose solve is in flight / waiting to be read, -1: none
-        unsigned long long version = 0;                // state_version at launch
+        hipEvent_t done = nullptr;                     // behind the result copy of the solve in flight
+        int cand = -1, pos = -1;                       // candidate / processing position of the solve in flight, -1: idle
+        int state = -1;                                // index of the pose state it started from (spec_states)
         int launch_id = 0;
+        int busy_wgs = 0;                              // workgroups of the last launch until its `done` completes (also after an abort)
         int lo = 0, hi = 0, nclu = 0;
         double th = 0.0;
-        unsigned long long commit_seen = 0;            // commits the stream is ordered behind
+    };
+    struct SpecState {                                 // a pose state solves start from
+        double* d_poses = nullptr;                     // d_cur (not owned) or a buffer of its own, [5 | 12][V]
+        bool owned = false;
+        hipEvent_t ready = nullptr;                    // its poses are complete (recorded on the stream that wrote them)
+        bool has_ready = false;
+        std::vector<int> cns;                          // the consensus set it stands for
+        int pos = -1;                                  // the accept at this processing position on top of its parent
+        int users = 0;                                 // solves in flight that read it
+        bool live = false;                             // committed, or in the tentative chain
+    };
+    struct SpecResult {                                // a finished solve waiting for its candidate's turn
+        bool valid = false, agree = false, retry_host = false;
+        int state = -1, child = -1;                    // started from / the tentative state its accept made
+        int lo = 0, hi = 0, nclu = 0;
+        ClusterOut o;
     };
     std::vector<SpecSlot> slots;
-    int spec_window = 4;
-    unsigned long long state_version = 1, commit_count = 0;
+    std::vector<SpecState> spec_states;
+    std::vector<int> tent;                             // tentative states, by position
+    std::vector<SpecResult> spec_res;                  // by processing position
+    int committed_state = -1;
+    int spec_head = -1, launch_pos = 0;                // next position to hand out / to launch; head -1: pipeline empty
+    int spec_window = 4, spec_ahead = 64;              // solves in flight / positions ahead of the head (IPC_SPEC_AHEAD)
+    double accept_rate = 0.5;                          // running mean over the recent verdicts: how far ahead it pays to assume "reject"
+    int helper_limit = 39;
+    unsigned long long commit_count = 0;
     hipEvent_t ev_commit = nullptr;
     int* h_abort = nullptr;                            // host-mapped: one word per slot, the launch id to give up
     int* d_abort = nullptr;
     int next_launch_id = 1;
     std::vector<int> pos_of;                           // candidate -> position in the processing order
-    long spec_hits = 0, spec_launches = 0, spec_wasted = 0;
+    long spec_hits = 0, spec_launches = 0, spec_wasted = 0, spec_tentative = 0, spec_promoted = 0;
+    double spec_t_launch = 0, spec_t_tent = 0, spec_t_total = 0;   // host seconds (IPC_SPEC_STATS)
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
@@ -701,6 +731,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         h->spec_window = (q && atoi(q) >= 9) ? 8 : 4;
     }
     if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) h->spec_window = std::max(1, std::min(32, atoi(sw))); }
+    if (const char* sa = getenv("IPC_SPEC_AHEAD")) { if (*sa) h->spec_ahead = std::max(1, std::min(1024, atoi(sa))); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
         else if (*cm && strcmp(cm, "persist")) { delete h; return fail(IPC_ERR_ARG, "IPC_CLUSTER_MODE must be 'persist' or 'host'"); }
@@ -810,11 +841,19 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     for (auto& sl : h->slots) {
         if (sl.st) hipStreamSynchronize(sl.st);
         delete sl.s2; delete sl.s3;
+        if (sl.done) hipEventDestroy(sl.done);
         if (sl.st) hipStreamDestroy(sl.st);
     }
+    for (auto& stt : h->spec_states) {
+        if (stt.owned) hipFree(stt.d_poses);
+        if (stt.ready) hipEventDestroy(stt.ready);
+    }
     if (h->d_prof || getenv("IPC_SPEC_STATS"))
-        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"launches\": %ld, \"cache_hits\": %ld, \"discarded\": %ld}}\n",
-                h->spec_window, h->spec_launches, h->spec_hits, h->spec_wasted);
+        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
+                        "\"tentative_states\": %ld, \"promoted\": %ld, \"host_s_in_checks\": %.3f, \"host_s_launching\": %.3f, "
+                        "\"host_s_tentative\": %.3f}}\n",
+                h->spec_window, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
+                h->spec_t_total, h->spec_t_launch, h->spec_t_tent);
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
     if (h->h_abort) hipHostFree(h->h_abort);
     delete h->persist2;
@@ -1552,17 +1591,17 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
 // then the threshold / iteration base of :50-52 and the x5 rule of consensus_utils.cpp:12-13.  members = the absorbed
 // edges in the order they were found, then k (:56).
 struct ClusterSpec { int lo, hi, nclu, iters; double th; std::vector<int> members; };
-static ClusterSpec cluster_of(const ipc_engine* h, int k)
+static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>& cns)
 {
     ClusterSpec c;
     c.lo = h->h_lo[k]; c.hi = h->h_hi[k];
-    std::vector<char> inc(h->cns.size(), 0);
+    std::vector<char> inc(cns.size(), 0);
     bool found = true;
     while (found) {
         found = false;
-        for (size_t q = 0; q < h->cns.size(); ++q) {
+        for (size_t q = 0; q < cns.size(); ++q) {
             if (inc[q]) continue;
-            const int e = h->cns[q];
+            const int e = cns[q];
             if (std::min(h->h_hi[e], c.hi) - std::max(h->h_lo[e], c.lo) <= 0) continue;
             c.lo = std::min(c.lo, h->h_lo[e]); c.hi = std::max(c.hi, h->h_hi[e]);
             inc[q] = 1; found = true;
@@ -1577,29 +1616,36 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k)
     if ((c.hi - c.lo) + (int)c.members.size() > 100) c.iters *= 5;            // consensus_utils.cpp:12-13
     return c;
 }
+static ClusterSpec cluster_of(const ipc_engine* h, int k) { return cluster_of(h, k, h->cns); }
 
-// IPC::agreementCheck's accept branch (src/consensus.cpp:69-71): the optimised window replaces the current poses, the
-// tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71), k joins the set.  Enqueued on `st`.
-static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
+// IPC::agreementCheck's accept branch (src/consensus.cpp:69-71) on the pose buffer `dst` ([5 | 12][V]): the optimised window
+// replaces the poses, the tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71).  Enqueued on `st`.
+static int apply_accept(ipc_engine* h, hipStream_t st, double* dst, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
 {
     if (h->dim == 3) {
-        HIPCHK(hipMemcpy2DAsync(h->d_cur + lo, sizeof(double) * h->V, X3, sizeof(double) * ld3, sizeof(double) * (hi - lo + 1), 12,
+        HIPCHK(hipMemcpy2DAsync(dst + lo, sizeof(double) * h->V, X3, sizeof(double) * ld3, sizeof(double) * (hi - lo + 1), 12,
                                 hipMemcpyDeviceToDevice, st));
         if (hi + 1 < h->V)
-            hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, h->d_cur);
+            hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, dst);
     } else {
         const double* xs[5] = {X2->x, X2->y, X2->th, X2->c, X2->s};
         for (int f = 0; f < 5; ++f)
-            HIPCHK(hipMemcpyAsync(h->d_cur + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(dst + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1), hipMemcpyDeviceToDevice, st));
         if (hi + 1 < h->V)
-            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, h->d_cur);
+            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, dst);
     }
     HIPCHK(hipGetLastError());
+    return IPC_OK;
+}
+// ... on the current poses; k joins the set.
+static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
+{
+    if (int rc = apply_accept(h, st, h->d_cur, lo, hi, X2, X3, ld3)) return rc;
     h->cns.push_back(k);
     return IPC_OK;
 }
 
-// ---- speculative window ---------------------------------------------------------------------------------
+// ---- speculative candidate pipeline (see ipc_engine::SpecSlot) ---------------------------------------------
 static int spec_ensure(ipc_engine* h)
 {
     if (!h->slots.empty()) return IPC_OK;
@@ -1608,157 +1654,329 @@ static int spec_ensure(ipc_engine* h)
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_abort), h->h_abort, 0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_commit, hipEventDisableTiming));
     h->slots.resize(h->spec_window);
-    // every workgroup of every solve in flight must be resident (they meet at grid barriers) and one workgroup fills a
-    // CU's register file: the window's workgroups may not exceed the CUs
-    const int helper_cap = std::max(0, h->n_cu / h->spec_window - 1);
+    if (h->max_helpers >= 0) h->helper_limit = std::min(h->helper_limit, h->max_helpers);
     for (int q = 0; q < h->spec_window; ++q) {
         ipc_engine::SpecSlot& sl = h->slots[q];
         HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (h->dim == 3) {
             sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s3->d_abort_word = h->d_abort + q;
-            if (h->max_helpers >= 0) sl.s3->max_helpers = h->max_helpers;
-            sl.s3->max_helpers = std::min(sl.s3->max_helpers, helper_cap);
             HIPCHK(sl.s3->reserve(h->V - 1, std::min(h->N, 48)));
         } else {
             sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s2->d_abort_word = h->d_abort + q;
-            if (h->max_helpers >= 0) sl.s2->max_helpers = h->max_helpers;
-            sl.s2->max_helpers = std::min(sl.s2->max_helpers, helper_cap);
             HIPCHK(sl.s2->reserve(h->V - 1, std::min(h->N, 48)));
         }
     }
     return IPC_OK;
 }
 
-// every solve in flight started from a state that no longer exists: tell it to stop, forget its result
-static void spec_invalidate(ipc_engine* h, int keep_slot)
+// a state object that nothing refers to any more (or a new one); its buffer is allocated once and kept
+static int spec_alloc_state(ipc_engine* h, int& idx)
 {
-    for (size_t q = 0; q < h->slots.size(); ++q) {
-        ipc_engine::SpecSlot& sl = h->slots[q];
-        if ((int)q == keep_slot || sl.cand < 0) continue;
-        __atomic_store_n(&h->h_abort[q], sl.launch_id, __ATOMIC_RELEASE);
-        sl.cand = -1;
-        ++h->spec_wasted;
+    idx = -1;
+    for (size_t i = 0; i < h->spec_states.size(); ++i) {
+        ipc_engine::SpecState& c = h->spec_states[i];
+        if (c.live || c.users != 0 || !c.owned) continue;
+        // (a dropped state's poses may still be on their way -- copies queued on the stream of the solve that made it:
+        // they would land on top of the new owner's)
+        if (c.has_ready && hipEventQuery(c.ready) != hipSuccess) continue;
+        idx = (int)i;
+        break;
     }
-    ++h->state_version;
+    if (idx < 0) {
+        h->spec_states.emplace_back();
+        idx = (int)h->spec_states.size() - 1;
+        ipc_engine::SpecState& n = h->spec_states[idx];
+        HIPCHK(hipMalloc(&n.d_poses, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V));
+        n.owned = true;
+        HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
+    }
+    ipc_engine::SpecState& n = h->spec_states[idx];
+    n.live = true; n.users = 0; n.pos = -1; n.has_ready = false; n.cns.clear();
+    return IPC_OK;
 }
 
-static int spec_launch(ipc_engine* h, int q, int k)
+// the pose state a solve of position p has to start from: the last tentative accept before p, else the committed state
+static int spec_state_at(const ipc_engine* h, int p)
+{
+    int st = h->committed_state;
+    for (int t : h->tent) { if (h->spec_states[t].pos < p) st = t; else break; }
+    return st;
+}
+
+static void spec_abort_slot(ipc_engine* h, int q)
 {
     ipc_engine::SpecSlot& sl = h->slots[q];
-    const ClusterSpec c = cluster_of(h, k);
-    sl.cand = k; sl.version = h->state_version; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th;
+    if (sl.cand < 0) return;
+    __atomic_store_n(&h->h_abort[q], sl.launch_id, __ATOMIC_RELEASE);
+    --h->spec_states[sl.state].users;
+    sl.cand = -1;
+    ++h->spec_wasted;
+}
+
+// everything behind position p (solves in flight, parked results, tentative states) assumed that p rejects: forget it
+static void spec_drop_after(ipc_engine* h, int p)
+{
+    for (size_t q = 0; q < h->slots.size(); ++q)
+        if (h->slots[q].cand >= 0 && h->slots[q].pos > p) spec_abort_slot(h, (int)q);
+    for (size_t r = (size_t)std::max(p + 1, 0); r < h->spec_res.size(); ++r) {
+        if (h->spec_res[r].valid) ++h->spec_wasted;
+        h->spec_res[r].valid = false;
+    }
+    while (!h->tent.empty() && h->spec_states[h->tent.back()].pos > p) {
+        h->spec_states[h->tent.back()].live = false;
+        h->tent.pop_back();
+    }
+    h->launch_pos = std::min(h->launch_pos, p + 1);
+}
+
+// the committed state as an object of the pipeline: the current poses (d_cur) and the current set
+static int spec_adopt_current(ipc_engine* h)
+{
+    if (h->committed_state >= 0) h->spec_states[h->committed_state].live = false;
+    int idx = -1;
+    for (size_t i = 0; i < h->spec_states.size(); ++i)
+        if (!h->spec_states[i].owned) { idx = (int)i; break; }
+    if (idx < 0) {
+        h->spec_states.emplace_back();
+        idx = (int)h->spec_states.size() - 1;
+        h->spec_states[idx].d_poses = h->d_cur;
+        h->spec_states[idx].owned = false;
+    }
+    ipc_engine::SpecState& c = h->spec_states[idx];
+    c.live = true; c.pos = -1; c.cns = h->cns; c.has_ready = false;      // (its readers wait for ev_commit instead)
+    h->committed_state = idx;
+    return IPC_OK;
+}
+
+struct SpecTimer {
+    double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit SpecTimer(double& a) : acc(a) {}
+    ~SpecTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+static int spec_launch(ipc_engine* h, int q, int p, int helpers)
+{
+    SpecTimer tm(h->spec_t_launch);
+    ipc_engine::SpecSlot& sl = h->slots[q];
+    const int k = h->order[p], si = spec_state_at(h, p);
+    ipc_engine::SpecState& S = h->spec_states[si];
+    const ClusterSpec c = cluster_of(h, k, S.cns);
+    sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th;
     sl.launch_id = h->next_launch_id++;
     if (h->next_launch_id == 0x7fffffff) h->next_launch_id = 1;
-    if (sl.commit_seen != h->commit_count) {            // the poses it starts from are those of the last commit
-        HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
-        sl.commit_seen = h->commit_count;
-    }
+    if (S.has_ready) HIPCHK(hipStreamWaitEvent(sl.st, S.ready, 0));
+    else if (!S.owned && h->commit_count) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
+    ++S.users;
     ++h->spec_launches;
+    if (h->dim == 3) sl.s3->max_helpers = helpers; else sl.s2->max_helpers = helpers;
     if (h->dim == 3) {
         sl.s3->launch_id = sl.launch_id;
-        HIPCHK(sl.s3->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V, c.lo, c.hi, c.members,
+        HIPCHK(sl.s3->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, S.d_poses, h->V, c.lo, c.hi, c.members,
                              h->h_from.data(), h->h_to.data(), c.iters));
     } else {
         sl.s2->launch_id = sl.launch_id;
-        HIPCHK(sl.s2->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, h->d_cur, h->V, c.lo, c.hi, c.members,
+        HIPCHK(sl.s2->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, S.d_poses, h->V, c.lo, c.hi, c.members,
                              h->h_from.data(), h->h_to.data(), c.iters));
     }
+    HIPCHK(hipEventRecord(sl.done, sl.st));
+    // (a kernel this slot was told to give up may still be running in front of the new one, never beside it)
+    sl.busy_wgs = std::max(sl.busy_wgs, h->dim == 3 ? sl.s3->workgroups() : sl.s2->workgroups());
+    return IPC_OK;
+}
+
+// The accept at position p (result parked, solver buffers of slot q still hold its poses) becomes a tentative state:
+// its parent's poses with the optimised window and the re-propagated tail, written on the slot's stream.
+static int spec_make_tentative(ipc_engine* h, int p, int q)
+{
+    SpecTimer tm(h->spec_t_tent);
+    ipc_engine::SpecResult& R = h->spec_res[p];
+    spec_drop_after(h, p);
+    int t = -1;
+    if (int rc = spec_alloc_state(h, t)) return rc;
+    ipc_engine::SpecSlot& sl = h->slots[q];
+    ipc_engine::SpecState& P = h->spec_states[R.state];
+    ipc_engine::SpecState& T = h->spec_states[t];
+    if (P.has_ready) HIPCHK(hipStreamWaitEvent(sl.st, P.ready, 0));
+    else if (!P.owned && h->commit_count) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
+    HIPCHK(hipMemcpyAsync(T.d_poses, P.d_poses, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice, sl.st));
+    if (h->dim == 3) {
+        const double* res = sl.s3->result_in_second() ? sl.s3->dev().Xn : sl.s3->dev().X;
+        if (int rc = apply_accept(h, sl.st, T.d_poses, R.lo, R.hi, nullptr, res, sl.s3->ld())) return rc;
+    } else {
+        const PoseArr X = sl.s2->result_in_second() ? sl.s2->dev().Xn : sl.s2->dev().X;
+        if (int rc = apply_accept(h, sl.st, T.d_poses, R.lo, R.hi, &X, nullptr, 0)) return rc;
+    }
+    HIPCHK(hipEventRecord(T.ready, sl.st));
+    T.has_ready = true;
+    T.cns = P.cns;
+    T.cns.push_back(h->order[p]);
+    T.pos = p;
+    h->tent.push_back(t);
+    R.child = t;
+    h->launch_pos = p + 1;
+    ++h->spec_tentative;
+    return IPC_OK;
+}
+
+// One turn of the pipeline: collect the solves that have ended, let the accepts among them (earliest first) move the
+// tip, start solves on the free slots.
+static int spec_pump(ipc_engine* h)
+{
+    const int B = (int)h->slots.size();
+    int fin_pos[64], fin_slot[64], nfin = 0;
+    for (int q = 0; q < B; ++q) {
+        ipc_engine::SpecSlot& sl = h->slots[q];
+        if (sl.cand < 0 && sl.busy_wgs == 0) continue;
+        const hipError_t e = hipEventQuery(sl.done);
+        if (e == hipErrorNotReady) continue;
+        HIPCHK(e);
+        sl.busy_wgs = 0;
+        if (sl.cand < 0) continue;                                            // (a solve that was told to give up has left the GPU)
+        ClusterOut o;
+        HIPCHK(h->dim == 3 ? sl.s3->fetch(o) : sl.s2->fetch(o));
+        const bool aborted = h->dim == 3 ? sl.s3->aborted() : sl.s2->aborted();
+        const int p = sl.pos;
+        --h->spec_states[sl.state].users;
+        const bool stale = aborted || p < h->spec_head || sl.state != spec_state_at(h, p);
+        sl.cand = -1;
+        if (stale) { ++h->spec_wasted; continue; }
+        ipc_engine::SpecResult& R = h->spec_res[p];
+        R = ipc_engine::SpecResult{};
+        R.valid = true; R.state = sl.state; R.lo = sl.lo; R.hi = sl.hi; R.nclu = sl.nclu; R.o = o;
+        R.retry_host = (o.flags & 2) && h->lm_retry;                          // (decided when its turn comes, by the damped solver)
+        R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
+        fin_pos[nfin] = p; fin_slot[nfin] = q; ++nfin;
+    }
+    for (int a = 0; a < nfin; ++a)                                            // by position (a handful at most)
+        for (int b = a + 1; b < nfin; ++b)
+            if (fin_pos[b] < fin_pos[a]) { std::swap(fin_pos[a], fin_pos[b]); std::swap(fin_slot[a], fin_slot[b]); }
+    for (int a = 0; a < nfin; ++a) {
+        const ipc_engine::SpecResult& R = h->spec_res[fin_pos[a]];
+        if (!R.valid || !R.agree) continue;                                   // (dropped by an earlier accept of this turn)
+        if (int rc = spec_make_tentative(h, fin_pos[a], fin_slot[a])) return rc;
+    }
+    // How many solves to keep in flight: the j-th one beyond the first unknown verdict is of use only if the j before it
+    // all reject -- (1 - accept rate)^j; below 5 % it is not started (3 in flight at 70 % accepts, the whole window at 13 %).
+    int target = B;
+    if (h->accept_rate > 0.01) {
+        const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
+        target = std::max(2, std::min(B, 1 + (int)r));
+    }
+    while (h->launch_pos < h->N && h->launch_pos - h->spec_head < h->spec_ahead) {
+        int q = -1, running = 0, busy = 0;
+        for (int i = 0; i < B; ++i) {
+            running += h->slots[i].cand >= 0;
+            if (h->slots[i].cand < 0 && (q < 0 || (h->slots[q].busy_wgs && !h->slots[i].busy_wgs))) q = i;   // (an empty stream first)
+        }
+        if (q < 0 || running >= target) break;
+        // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
+        // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
+        // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
+        for (int i = 0; i < B; ++i) if (i != q) busy += h->slots[i].busy_wgs;
+        const int helpers = std::min(h->helper_limit, h->n_cu - 8 - busy - 1);
+        if (helpers < std::min(8, h->helper_limit) && running > 0) break;                     // (wait for a solve to leave)
+        const int tip = spec_state_at(h, h->launch_pos);
+        if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) break;
+        if (int rc = spec_launch(h, q, h->launch_pos, std::max(0, helpers))) return rc;
+        ++h->launch_pos;
+    }
+    return IPC_OK;
+}
+
+// stop everything in flight and forget every result and tentative state (the poses / the set change from outside, or the
+// caller leaves the processing order)
+static int spec_reset(ipc_engine* h)
+{
+    for (size_t q = 0; q < h->slots.size(); ++q) spec_abort_slot(h, (int)q);
+    for (auto& sl : h->slots) HIPCHK(hipStreamSynchronize(sl.st));
+    for (auto& R : h->spec_res) R.valid = false;
+    for (int t : h->tent) h->spec_states[t].live = false;
+    h->tent.clear();
+    if (h->commit_count) HIPCHK(hipEventSynchronize(h->ev_commit));
+    h->spec_head = -1;
     return IPC_OK;
 }
 
 static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
 {
     if (int rc = spec_ensure(h)) return rc;
-    const int B = (int)h->slots.size();
-    auto find = [&](int cand) {
-        for (int q = 0; q < B; ++q)
-            if (h->slots[q].cand == cand && h->slots[q].version == h->state_version) return q;
-        return -1;
-    };
-    auto free_slot = [&]() {
-        for (int q = 0; q < B; ++q) if (h->slots[q].cand < 0) return q;
-        return -1;
-    };
-    int qk = find(k);
-    if (qk >= 0) ++h->spec_hits;
-    else {
-        qk = free_slot();
-        if (qk < 0) {                                   // window full of other candidates (a caller off the processing order)
-            spec_invalidate(h, -1);
-            qk = 0;
-        }
-        if (int rc = spec_launch(h, qk, k)) return rc;
+    SpecTimer tm(h->spec_t_total);
+    const int p = h->pos_of[k];
+    if (h->spec_head != p) {                           // first call, or a caller off the processing order: start over at k
+        if (int rc = spec_reset(h)) return rc;
+        if (int rc = spec_adopt_current(h)) return rc;
+        h->spec_res.assign(h->N, ipc_engine::SpecResult{});
+        h->spec_head = p;
+        h->launch_pos = p;
     }
-    // keep the window full: the candidates that follow k in the processing order, from the same state
-    for (int ahead = 1; ahead < B; ++ahead) {
-        const int p = h->pos_of[k] + ahead;
-        if (p >= h->N) break;
-        const int c = h->order[p];
-        if (find(c) >= 0) continue;
-        const int q = free_slot();
-        if (q < 0) break;
-        if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->cns.size() + 1)) break;
-        if (int rc = spec_launch(h, q, c)) return rc;
+    for (unsigned spin = 0;; ++spin) {
+        if (int rc = spec_pump(h)) return rc;
+        if (h->spec_res[p].valid) break;
+        bool running = false;
+        for (auto& sl : h->slots) running = running || sl.cand >= 0;
+        if (!running) return fail(IPC_ERR_STATE, "ipc_agreement_check: the pipeline lost candidate %d", k);
+        if (spin > 64) std::this_thread::yield();
     }
-    ipc_engine::SpecSlot& sl = h->slots[qk];
-    ClusterOut o;
-    HIPCHK(h->dim == 3 ? sl.s3->wait(o) : sl.s2->wait(o));
-    const int lo = sl.lo, hi = sl.hi, nclu = sl.nclu;
-    const double th = sl.th;
-    sl.cand = -1;
-    if ((o.flags & 2) && h->lm_retry) {
+    ipc_engine::SpecResult R = h->spec_res[p];
+    h->spec_res[p].valid = false;
+    ++h->spec_hits;
+    ClusterOut o = R.o;
+    const double th = R.nclu ? h->prm.slow_reject_th : h->prm.fast_reject_th;
+    bool agree = R.agree;
+    if (R.retry_host) {
         // the capacitance factorisation met a non-positive pivot: redo this check with the host-driven solver, which
         // retries with Levenberg damping as g2o does (rare: degenerate information matrices, NaN poses)
-        if (h->commit_count) HIPCHK(hipStreamWaitEvent(h->own_stream, h->ev_commit, 0));
+        if (int rc = spec_reset(h)) return rc;
         const ClusterSpec c = cluster_of(h, k);
         HIPCHK(cluster_solve(h, h->d_chain, h->d_cur, c.lo, c.hi, c.members, c.iters, o));
-        const bool agree_lm = !(o.max_chi2 > th);
-        if (agree_lm) {
-            spec_invalidate(h, -1);
+        agree = !(o.max_chi2 > th);
+        if (agree) {
             int rld = 0;
             if (h->dim == 3) {
                 const double* res = cluster_result3(h, rld);
-                if (int rc = commit_accept(h, h->own_stream, k, lo, hi, nullptr, res, rld)) return rc;
+                if (int rc = commit_accept(h, h->own_stream, k, R.lo, R.hi, nullptr, res, rld)) return rc;
             } else {
                 const PoseArr X = cluster_result2(h);
-                if (int rc = commit_accept(h, h->own_stream, k, lo, hi, &X, nullptr, 0)) return rc;
+                if (int rc = commit_accept(h, h->own_stream, k, R.lo, R.hi, &X, nullptr, 0)) return rc;
             }
             HIPCHK(hipEventRecord(h->ev_commit, h->own_stream));
             ++h->commit_count;
         }
-        *agrees = agree_lm ? 1 : 0;
-        fill_info(info, lo, hi, nclu, o);
-        return IPC_OK;
-    }
-    const bool agree = !(o.max_chi2 > th);                                    // consensus_utils.cpp:17-21
-    if (agree) {                                                              // :69-71
-        spec_invalidate(h, -1);
-        if (h->dim == 3) {
-            const double* res = sl.s3->result_in_second() ? sl.s3->dev().Xn : sl.s3->dev().X;
-            if (int rc = commit_accept(h, sl.st, k, lo, hi, nullptr, res, sl.s3->ld())) return rc;
-        } else {
-            const PoseArr X = sl.s2->result_in_second() ? sl.s2->dev().Xn : sl.s2->dev().X;
-            if (int rc = commit_accept(h, sl.st, k, lo, hi, &X, nullptr, 0)) return rc;
+        // (spec_head is -1: the next call starts the pipeline again from the poses as they are now)
+    } else {
+        if (agree) {                                                          // :69-71 -- the tentative state becomes THE state
+            if (h->tent.empty() || h->tent.front() != R.child || R.child < 0)
+                return fail(IPC_ERR_STATE, "ipc_agreement_check: accept of candidate %d without its state", k);
+            ipc_engine::SpecState& T = h->spec_states[R.child];
+            h->spec_states[h->committed_state].live = false;
+            h->committed_state = R.child;
+            h->tent.erase(h->tent.begin());
+            h->cns = T.cns;
+            // the poses everyone outside the pipeline reads
+            HIPCHK(hipStreamWaitEvent(h->own_stream, T.ready, 0));
+            HIPCHK(hipMemcpyAsync(h->d_cur, T.d_poses, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice,
+                                  h->own_stream));
+            HIPCHK(hipEventRecord(h->ev_commit, h->own_stream));
+            ++h->commit_count;
+            ++h->spec_promoted;
         }
-        HIPCHK(hipEventRecord(h->ev_commit, sl.st));
-        ++h->commit_count;
-        sl.commit_seen = h->commit_count;
+        h->spec_head = p + 1;
+        h->accept_rate += 0.08 * ((agree ? 1.0 : 0.0) - h->accept_rate);
+        if (h->spec_head >= h->N) { if (int rc = spec_reset(h)) return rc; }
     }
     *agrees = agree ? 1 : 0;
-    fill_info(info, lo, hi, nclu, o);
+    fill_info(info, R.lo, R.hi, R.nclu, o);
     return IPC_OK;
 }
 
-// the poses / the set are about to be read or edited from outside the window: nothing in flight may outlive that
+// the poses / the set are about to be read or edited from outside the pipeline: nothing in flight may outlive that
 static int spec_quiesce(ipc_engine* h, bool state_changes)
 {
     if (h->slots.empty()) return IPC_OK;
-    if (state_changes) spec_invalidate(h, -1);
+    if (state_changes) return spec_reset(h);
     if (h->commit_count) HIPCHK(hipEventSynchronize(h->ev_commit));
-    if (state_changes)
-        for (auto& sl : h->slots) HIPCHK(hipStreamSynchronize(sl.st));
     return IPC_OK;
 }
 

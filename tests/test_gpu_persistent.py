@@ -171,6 +171,23 @@ def test_speculative_window_is_exact(window):
         assert np.float64(ia.max_chi2).tobytes() == np.float64(ib.max_chi2).tobytes()
 
 
+def test_pipeline_is_bitwise_on_c1_clusters_of_253_loops():
+    """BASELINE configs[0] through the pipeline (71 % of the candidates accepted: tentative states made and dropped all the
+    time, pose buffers recycled while copies are still queued) -- every check returns the bits of the one-at-a-time run,
+    run after run."""
+    import bench
+    g, cfg, _ = bench.build_workload("C1")
+    e1 = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1)
+    order = e1.candidate_order()
+    ref = _run(e1, order)
+    for rep in range(2):
+        ew = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=8)
+        _assert_bitwise(ref, _run(ew, order))
+        assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
+        assert np.array_equal(e1.getMaxConsensusSet(), ew.getMaxConsensusSet())
+        ew.close()
+
+
 def test_speculative_window_se3_is_exact():
     import bench
     g, cfg, _ = bench.build_workload("C4s")
