@@ -1030,7 +1030,7 @@ private:
     bool aborted_ = false;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
     int* d_int_ = nullptr;
-    static constexpr int kTabSlots = 4;
+    static constexpr int kTabSlots = 8;
     int* h_tab_[kTabSlots] = {};
     hipEvent_t ev_tab_[kTabSlots] = {};
     bool tab_used_[kTabSlots] = {};

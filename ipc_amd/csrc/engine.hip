@@ -728,7 +728,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     {   // window: as many solves in flight as there are hardware queues to run them side by side (IPC_SPEC_WINDOW overrides)
         const char* q = getenv("GPU_MAX_HW_QUEUES");
-        h->spec_window = (q && atoi(q) >= 9) ? 8 : 4;
+        const int nq = q ? atoi(q) : 4;
+        h->spec_window = nq >= 13 ? 10 : (nq >= 9 ? 8 : 4);          // (+ the engine's own stream and its two side streams)
     }
     if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) h->spec_window = std::max(1, std::min(32, atoi(sw))); }
     if (const char* sa = getenv("IPC_SPEC_AHEAD")) { if (*sa) h->spec_ahead = std::max(1, std::min(1024, atoi(sa))); }
@@ -1530,6 +1531,61 @@ __global__ void k_se3_propagate_tail(int V, int start, const double* rec, int st
     }
 }
 
+// The accept branch of IPC::agreementCheck (src/consensus.cpp:69-71) in one launch: dst = parent outside the window, the
+// optimised poses inside lo..hi, then propagateCurrentGuess (consensus_utils.cpp:61-71) down the tail -- the serial
+// compose of k_se*_propagate_tail, same operations in the same order, but with the measurement records staged through
+// LDS by the whole workgroup a chunk at a time (the one lane that composes no longer waits for memory at every pose).
+// NF = 5 (SE2: x, y, theta, cos, sin) or 12 (SE3: R row-major, t); X = the solver's arrays [NF][ldx], window index 0 = lo.
+constexpr int kAcceptChunk = 256;
+template <int NF>
+__global__ __launch_bounds__(256) void k_apply_accept(int V, int lo, int hi, const double* parent, const double* X, int ldx,
+                                                      const double* rec, int stride, double* dst)
+{
+    constexpr int NR = NF == 5 ? 3 : 12;                       // record fields the compose reads
+    __shared__ double sh[kAcceptChunk * NR];
+    const int tid = threadIdx.x;
+    for (int q = tid; q < NF * V; q += 256) {
+        const int f = q / V, i = q - f * V;
+        if (i >= lo && i <= hi) dst[q] = X[(size_t)f * ldx + (i - lo)];
+        else if (i < lo && dst != parent) dst[q] = parent[q];
+    }
+    double st[NF];
+    if (tid == 0)
+        for (int f = 0; f < NF; ++f) st[f] = X[(size_t)f * ldx + (hi - lo)];
+    for (int base = hi + 1; base < V; base += kAcceptChunk) {
+        const int cnt = min(kAcceptChunk, V - base);
+        __syncthreads();
+        for (int q = tid; q < cnt * NR; q += 256) {
+            const int r = q / cnt, i = q - r * cnt;
+            int field;
+            if (NF == 5) field = r == 0 ? (int)F_TZX : (r == 1 ? (int)F_TZY : (int)F_THZ);
+            else field = r < 9 ? (int)G_RZ + r : (int)G_TZ + (r - 9);
+            sh[r * kAcceptChunk + i] = rec[(size_t)field * stride + base + i - 1];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < cnt; ++i) {
+                if (NF == 5) {
+                    const double tx = sh[i], ty = sh[kAcceptChunk + i];
+                    st[0] += st[3] * tx - st[4] * ty;
+                    st[1] += st[4] * tx + st[3] * ty;
+                    st[2] = normalize_theta(st[2] + sh[2 * kAcceptChunk + i]);
+                    sincos_pi(st[2], st[4], st[3]);
+                } else {
+                    double Rz[9], tz[3], Rn[9], d[3];
+                    for (int q = 0; q < 9; ++q) Rz[q] = sh[q * kAcceptChunk + i];
+                    for (int q = 0; q < 3; ++q) tz[q] = sh[(9 + q) * kAcceptChunk + i];
+                    m3_mul(st, Rz, Rn);
+                    m3_vec(st, tz, d);
+                    for (int q = 0; q < 3; ++q) st[9 + q] += d[q];
+                    for (int q = 0; q < 9; ++q) st[q] = Rn[q];
+                }
+                for (int f = 0; f < NF; ++f) dst[(size_t)f * V + base + i] = st[f];
+            }
+        }
+    }
+}
+
 static PoseArr pose_arr(double* base, int V)
 {
     return PoseArr{base, base + (size_t)V, base + 2 * (size_t)V, base + 3 * (size_t)V, base + 4 * (size_t)V};
@@ -1620,27 +1676,23 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k) { return cluster_of(h,
 
 // IPC::agreementCheck's accept branch (src/consensus.cpp:69-71) on the pose buffer `dst` ([5 | 12][V]): the optimised window
 // replaces the poses, the tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71).  Enqueued on `st`.
-static int apply_accept(ipc_engine* h, hipStream_t st, double* dst, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
+static int apply_accept(ipc_engine* h, hipStream_t st, double* dst, const double* parent, int lo, int hi, const PoseArr* X2,
+                        const double* X3, int ld3)
 {
-    if (h->dim == 3) {
-        HIPCHK(hipMemcpy2DAsync(dst + lo, sizeof(double) * h->V, X3, sizeof(double) * ld3, sizeof(double) * (hi - lo + 1), 12,
-                                hipMemcpyDeviceToDevice, st));
-        if (hi + 1 < h->V)
-            hipLaunchKernelGGL(k_se3_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, dst);
-    } else {
-        const double* xs[5] = {X2->x, X2->y, X2->th, X2->c, X2->s};
-        for (int f = 0; f < 5; ++f)
-            HIPCHK(hipMemcpyAsync(dst + (size_t)f * h->V + lo, xs[f], sizeof(double) * (hi - lo + 1), hipMemcpyDeviceToDevice, st));
-        if (hi + 1 < h->V)
-            hipLaunchKernelGGL(k_se2_propagate_tail, dim3(1), dim3(64), 0, st, h->V, hi, h->d_chain, h->estride, dst);
-    }
+    if (h->dim == 3)
+        hipLaunchKernelGGL(k_apply_accept<12>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X3, ld3, h->d_chain, h->estride, dst);
+    else if (X2->th - X2->y != X2->y - X2->x || X2->c - X2->th != X2->y - X2->x || X2->s - X2->c != X2->y - X2->x)
+        return fail(IPC_ERR_STATE, "apply_accept: the solver's pose arrays are not rows of one block");
+    else                                            // (x, y, th, c, s: rows of one block, ClusterSolver2 / PersistSe2::carve)
+        hipLaunchKernelGGL(k_apply_accept<5>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X2->x, (int)(X2->y - X2->x), h->d_chain,
+                           h->estride, dst);
     HIPCHK(hipGetLastError());
     return IPC_OK;
 }
 // ... on the current poses; k joins the set.
 static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
 {
-    if (int rc = apply_accept(h, st, h->d_cur, lo, hi, X2, X3, ld3)) return rc;
+    if (int rc = apply_accept(h, st, h->d_cur, h->d_cur, lo, hi, X2, X3, ld3)) return rc;
     h->cns.push_back(k);
     return IPC_OK;
 }
@@ -1655,6 +1707,8 @@ static int spec_ensure(ipc_engine* h)
     HIPCHK(hipEventCreateWithFlags(&h->ev_commit, hipEventDisableTiming));
     h->slots.resize(h->spec_window);
     if (h->max_helpers >= 0) h->helper_limit = std::min(h->helper_limit, h->max_helpers);
+    // (workspaces for clusters of up to 256 loops up front, 9 MB (SE2) / 37 MB (SE3) per slot: growing them later means
+    // hipFree, which waits for every solve in flight -- 0.36 s of a 2.3 s C2 run when the slots started at 48 loops)
     for (int q = 0; q < h->spec_window; ++q) {
         ipc_engine::SpecSlot& sl = h->slots[q];
         HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
@@ -1662,11 +1716,11 @@ static int spec_ensure(ipc_engine* h)
         if (h->dim == 3) {
             sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s3->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s3->reserve(h->V - 1, std::min(h->N, 48)));
+            HIPCHK(sl.s3->reserve(h->V - 1, std::min(h->N, 256)));
         } else {
             sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s2->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s2->reserve(h->V - 1, std::min(h->N, 48)));
+            HIPCHK(sl.s2->reserve(h->V - 1, std::min(h->N, 256)));
         }
     }
     return IPC_OK;
@@ -1800,13 +1854,12 @@ static int spec_make_tentative(ipc_engine* h, int p, int q)
     ipc_engine::SpecState& T = h->spec_states[t];
     if (P.has_ready) HIPCHK(hipStreamWaitEvent(sl.st, P.ready, 0));
     else if (!P.owned && h->commit_count) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
-    HIPCHK(hipMemcpyAsync(T.d_poses, P.d_poses, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice, sl.st));
     if (h->dim == 3) {
         const double* res = sl.s3->result_in_second() ? sl.s3->dev().Xn : sl.s3->dev().X;
-        if (int rc = apply_accept(h, sl.st, T.d_poses, R.lo, R.hi, nullptr, res, sl.s3->ld())) return rc;
+        if (int rc = apply_accept(h, sl.st, T.d_poses, P.d_poses, R.lo, R.hi, nullptr, res, sl.s3->ld())) return rc;
     } else {
         const PoseArr X = sl.s2->result_in_second() ? sl.s2->dev().Xn : sl.s2->dev().X;
-        if (int rc = apply_accept(h, sl.st, T.d_poses, R.lo, R.hi, &X, nullptr, 0)) return rc;
+        if (int rc = apply_accept(h, sl.st, T.d_poses, P.d_poses, R.lo, R.hi, &X, nullptr, 0)) return rc;
     }
     HIPCHK(hipEventRecord(T.ready, sl.st));
     T.has_ready = true;
