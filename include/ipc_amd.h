@@ -206,7 +206,12 @@ int ipc_incremental_reset(ipc_engine_t* h);
  * (:50-52), isAgreeingWithCurrentState on chain [lo,hi] + cluster loops + candidate from the
  * current poses (consensus_utils.cpp:7-22); on agreement the poses are kept, k joins the
  * consensus set and the tail is re-propagated (propagateCurrentGuess, consensus_utils.cpp:61-71);
- * otherwise the state is untouched.  *agrees = 1 / 0.  info may be NULL. */
+ * otherwise the state is untouched.  *agrees = 1 / 0.  info may be NULL.
+ * Called in the processing order (ipc_candidate_order) the call finds most results waiting: the library solves ahead of
+ * the caller, several candidates at a time (IPC_SPEC_WINDOW, IPC_SPEC_AHEAD), from the current state and from the states
+ * finished accepts leave behind, and uses a result only if the state it started from is the committed one when its turn
+ * comes -- decisions, iteration counts and chi2 are those of the one-at-a-time loop, bit for bit.  Any other order, and
+ * any edit of the set, is served correctly as well (the work done ahead is thrown away). */
 int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_check_info_t* info);
 
 /* IPC::getMaxConsensusSet (include/ipc/consensus.hpp:16): candidate FILE indices in set order. */

@@ -570,7 +570,7 @@ struct ipc_engine {
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
     int max_helpers = -1;                              // IPC_PERSIST_HELPERS
-    // Speculative candidate pipeline of the faithful mode (IPC_SPEC_WINDOW solves in flight, default 8; 1 = off).
+    // Speculative candidate pipeline of the faithful mode (IPC_SPEC_WINDOW solves in flight, default 10; 1 = off).
     // A rejected candidate leaves the state untouched (reference src/consensus.cpp:63-67), so the checks of the candidates
     // that FOLLOW in the processing order can start from the same state before its verdict is known; and the state an
     // accept leaves behind is known as soon as ITS solve ends, so the candidates after it start from that state while
