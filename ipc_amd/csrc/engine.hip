@@ -1034,6 +1034,9 @@ static PoseArr pose_arr(double* base, int V);
 static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src, int lo, int hi, const std::vector<int>& members,
                                 int iters, ClusterOut& o, bool force_host = false)
 {
+    // (nothing of the candidate pipeline may share the GPU with this launch: its workgroups and the pipeline's together
+    // could exceed the CUs, and workgroups that wait at grid barriers must all be resident)
+    if (!h->slots.empty() && h->spec_head >= 0) { if (int rc = spec_quiesce(h, true)) return hipErrorUnknown; }
     h->last_persist = !force_host && h->persist && PersistSolver<PersistSe2>::fits(hi - lo, (int)members.size());
     if (h->last_persist) {
         if (h->dim == 3) {

@@ -188,6 +188,28 @@ def test_pipeline_is_bitwise_on_c1_clusters_of_253_loops():
         ew.close()
 
 
+def test_pipeline_is_left_mid_run_for_other_entry_points():
+    """A caller that stops asking after a few candidates leaves solves in flight and results parked; the final map, the
+    matrix mode and a second run must not care (they share the GPU's CUs with nothing of the pipeline)."""
+    import bench
+    g, cfg, _ = bench.build_workload("C1")
+    e1, ew = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1), _engine(g, cfg, "persist", IPC_SPEC_WINDOW=10)
+    order = e1.candidate_order()
+    acc = np.zeros(g.N, dtype=np.uint8)
+    for e in (e1, ew):
+        e.reset()
+        for k in order[:60]:
+            acc[k] = e.agreementCheck(int(k))
+    pa, ia = e1.final_optimize(acc)
+    pb, ib = ew.final_optimize(acc)
+    assert np.array_equal(pa.view(np.uint64), pb.view(np.uint64)) and ia.iterations == ib.iterations
+    ba, aa = e1.run()
+    bb, ab = ew.run()
+    assert np.array_equal(ba, bb) and np.array_equal(aa, ab)
+    _assert_bitwise(_run(e1, order[:90]), _run(ew, order[:90]))
+    assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
+
+
 def test_speculative_window_se3_is_exact():
     import bench
     g, cfg, _ = bench.build_workload("C4s")
