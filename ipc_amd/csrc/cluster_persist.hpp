@@ -734,15 +734,28 @@ template <class T>
 __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev D0, typename T::Dev D1, PersistArgs P)
 {
     // D0: the problem as carved by the host; D1: the same with the committed / trial buffers exchanged (a commit of
-    // the dog-leg is a switch between the two views, both stay in the kernel-argument segment)
-    const typename T::Dev* Dp = &D0;
+    // the dog-leg is a switch between the two views).  Both are read where they are, in the kernel-argument segment:
+    // taking the address of the by-value arguments makes the compiler copy them to scratch, and every D->member of every
+    // phase body then starts with a scratch load (one more dependent memory round trip per phase; 608 of them in the
+    // kernel).  Through the segment pointer they are scalar loads of the constant address space.
+    using Dev = typename T::Dev;
+    constexpr size_t kView1 = (sizeof(Dev) + alignof(Dev) - 1) / alignof(Dev) * alignof(Dev);     // offset of D1 behind D0
+    const __attribute__((address_space(4))) char* kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    int vsel = 0;                                             // which view is the committed one (uniform)
+    // a phase's copy of the view: scalar loads of the members the phase uses, nothing of it lives across phases
+    auto view = [&](int sel) {
+        Dev d;
+        __builtin_memcpy(&d, kargs + (__builtin_amdgcn_readfirstlane(sel) ? kView1 : 0), sizeof(Dev));
+        return d;
+    };
+    (void)D0; (void)D1;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
     GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error, P.prof};
-    const int L = Dp->L, nl = Dp->nl, ld = Dp->ld;
+    const int L = D0.L, nl = D0.nl, ld = D0.ld;
     const int n = T::kD * nl;
-    double* A = Dp->S;
-    double* Lf = Dp->S + (size_t)(n + 1) * n;
+    double* A = D0.S;
+    double* Lf = D0.S + (size_t)(n + 1) * n;
     bool alive = true;
 
     auto assemble_share = [&](const typename T::Dev& Dv) {
@@ -759,7 +772,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             if (__hip_atomic_load(&P.ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) return;
             if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // the leader's ps / Gamma / loop errors
             __syncthreads();
-            assemble_share(__hip_atomic_load(&P.ctl->le_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? D1 : D0);
+            { const Dev Dv = view(__hip_atomic_load(&P.ctl->le_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); assemble_share(Dv); }
             if (!grid_barrier(gb)) return;                                                   // B2: the system is assembled
             pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
             if (!alive) return;
@@ -770,20 +783,21 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     const unsigned long long tk0 = prof_now();
     const int nidx = L + nl + 1, nblk = (nidx + 255) / 256;
     int n_commit = 0;
-    lead_for(L + 1, [&](int i) { T::load_initial((*Dp), P.src, P.src_ld, i); });
+    { const Dev Dv = view(0); lead_for(L + 1, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
 
     auto evaluate = [&](bool trial) {
         double tot[1];
-        lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::eval((*Dp), trial, i, v); });
+        const Dev Dv = view(vsel);
+        lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::eval(Dv, trial, i, v); });
         return tot[0];
     };
     // H h_gn = b through the capacitance system; returns the solver's info word
     auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
         unsigned long long t0 = prof_now();
-        lead_for(nidx, [&](int i) { T::force((*Dp), i); });
-        { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::b((*Dp), i, v); }); bb = tot[0]; }
-        { double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::bHb_psi((*Dp), i, v); }); bHb = tot[0]; }
-        lead_scan(Dp->ps, T::kNPS, L, ld, lds);
+        { const Dev Dv = view(vsel); lead_for(nidx, [&](int i) { T::force(Dv, i); }); }
+        { const Dev Dv = view(vsel); double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::b(Dv, i, v); }); bb = tot[0]; }
+        { const Dev Dv = view(vsel); double tot[1]; lead_reduce<1>(nblk, lds, tot, [&](int i, double (&v)[1]) { T::bHb_psi(Dv, i, v); }); bHb = tot[0]; }
+        { const Dev Dv = view(vsel); lead_scan(Dv.ps, T::kNPS, L, ld, lds); }
         prof_add(P.prof, kProfPre, t0); t0 = prof_now();
         // hand the assembly's inputs to the helpers, factor together
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -796,22 +810,22 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         }
         alive = grid_barrier(gb);                                                            // B1
         prof_add(P.prof, kProfHandoff, t0); t0 = prof_now();
-        assemble_share((*Dp));
+        { const Dev Dv = view(vsel); assemble_share(Dv); }
         if (alive) alive = grid_barrier(gb);                                                 // B2
         prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
         if (alive) info = pchol_factor(A, Lf, P.dinv, n, gb, lds, alive);
         prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
-        pchol_backsolve(Lf, n, Dp->rhs, lds, P.prof);
+        { const Dev Dv = view(vsel); pchol_backsolve(Lf, n, Dv.rhs, lds, P.prof); }
         prof_add(P.prof, kProfBacksolve, t0); t0 = prof_now();
-        lead_for(nl, [&](int l) { T::nu((*Dp), l); });
-        lead_for(L + 2, [&](int j) { T::events((*Dp), j); });
-        lead_scan(Dp->nd, T::kNND, L, ld, lds);
-        lead_for(nidx, [&](int i) { T::rho((*Dp), i); });
-        lead_scan(Dp->sc, T::kSC1, L, ld, lds);
-        lead_for(nidx, [&](int i) { T::term((*Dp), i); });
-        lead_scan(Dp->sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds);
-        { double tot[2]; lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::h((*Dp), i, v); }); hh = tot[0]; bh = tot[1]; }
+        { const Dev Dv = view(vsel); lead_for(nl, [&](int l) { T::nu(Dv, l); }); }
+        { const Dev Dv = view(vsel); lead_for(L + 2, [&](int j) { T::events(Dv, j); }); }
+        { const Dev Dv = view(vsel); lead_scan(Dv.nd, T::kNND, L, ld, lds); }
+        { const Dev Dv = view(vsel); lead_for(nidx, [&](int i) { T::rho(Dv, i); }); }
+        { const Dev Dv = view(vsel); lead_scan(Dv.sc, T::kSC1, L, ld, lds); }
+        { const Dev Dv = view(vsel); lead_for(nidx, [&](int i) { T::term(Dv, i); }); }
+        { const Dev Dv = view(vsel); lead_scan(Dv.sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds); }
+        { const Dev Dv = view(vsel); double tot[2]; lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::h(Dv, i, v); }); hh = tot[0]; bh = tot[1]; }
         prof_add(P.prof, kProfPost, t0);
         if (P.prof && tid == 0) P.prof[kProfIterations] += 1;
         return info;
@@ -855,7 +869,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             else {
                 stepType = 2;
                 double tot[2];
-                lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::blend((*Dp), alpha, i, v); });
+                { const Dev Dv = view(vsel); lead_reduce<2>(nblk, lds, tot, [&](int i, double (&v)[2]) { T::blend(Dv, alpha, i, v); }); }
                 const double c = tot[0], bma = tot[1];
                 const double hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
@@ -869,7 +883,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             const double bhdl = pcoef * bb + qcoef * bh;
             double linearGain = -1 * hdlHhdl + 2 * bhdl;
             double changed[1];
-            lead_reduce<1>(nblk, lds, changed, [&](int i, double (&v)[1]) { T::update((*Dp), pcoef, qcoef, i, v); });
+            { const Dev Dv = view(vsel); lead_reduce<1>(nblk, lds, changed, [&](int i, double (&v)[1]) { T::update(Dv, pcoef, qcoef, i, v); }); }
             const bool anyChanged = changed[0] != 0.0;
             const double newChi = evaluate(true);
             ++o.evals;
@@ -880,7 +894,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
                 goodStep = true;
                 currentChi = newChi;
                 ++n_commit;
-                Dp = (n_commit & 1) ? &D1 : &D0;
+                vsel = n_commit & 1;
             }
             if (rho > 0.75) delta = fmax(delta, 3 * hdlNorm);
             else if (rho < 0.25) delta *= 0.5;
@@ -907,12 +921,13 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         grid_barrier(gb);
     }
     // per-edge chi2 of the committed state and their maximum (a NaN makes the maximum NaN: `chi2 > th` is then false)
-    lead_for(nidx, [&](int i) { T::chi_edges((*Dp), i); });
+    { const Dev Dv = view(vsel); lead_for(nidx, [&](int i) { T::chi_edges(Dv, i); }); }
     {
         double mx = 0.0;
         bool nan = false;
+        const Dev Dv = view(vsel);
         for (int i = tid; i < L + nl; i += kPT) {
-            const double c = gptr(Dp->chi_edges)[i];
+            const double c = gptr(Dv.chi_edges)[i];
             if (c != c) nan = true; else mx = fmax(mx, c);
         }
         mx = wave_max(mx);
