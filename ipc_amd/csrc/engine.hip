@@ -627,6 +627,9 @@ struct ipc_engine {
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
+// One pipeline at a time per process: the workgroup budget of spec_pump counts this engine's solves only, and two
+// pipelines that fill the GPU between them could each end up with half-resident kernels waiting for the other's CUs.
+static ipc_engine* g_active_pipeline = nullptr;
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
@@ -819,6 +822,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
     spec_quiesce(h, true);
+    if (g_active_pipeline == h) g_active_pipeline = nullptr;
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
@@ -1958,6 +1962,13 @@ static int spec_reset(ipc_engine* h)
 static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
 {
     if (int rc = spec_ensure(h)) return rc;
+    if (g_active_pipeline && g_active_pipeline != h) {
+        HIPCHK(hipSetDevice(g_active_pipeline->device));
+        const int rc = spec_reset(g_active_pipeline);
+        HIPCHK(hipSetDevice(h->device));
+        if (rc) return rc;
+    }
+    g_active_pipeline = h;
     SpecTimer tm(h->spec_t_total);
     const int p = h->pos_of[k];
     if (h->spec_head != p) {                           // first call, or a caller off the processing order: start over at k

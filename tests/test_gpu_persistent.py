@@ -210,6 +210,33 @@ def test_pipeline_is_left_mid_run_for_other_entry_points():
     assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
 
 
+def test_two_engines_asked_in_turn():
+    """Two engines whose callers alternate: only one pipeline owns the GPU at a time (the other's work ahead is dropped
+    when the turn changes) -- results as if each had run alone."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    ga = synth.inject_outliers(synth._se2_graph(400, 24, seed=81, laps=3.0, name="a"), 40, seed=2)
+    gb = synth.inject_outliers(synth._se2_graph(300, 20, seed=5, laps=2.0, name="b"), 30, seed=3)
+    cfg = Config()
+    ref = []
+    for g in (ga, gb):
+        e = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1)
+        ref.append(_run(e, e.candidate_order()))
+        e.close()
+    ea, eb = _engine(ga, cfg, "persist", IPC_SPEC_WINDOW=10), _engine(gb, cfg, "persist", IPC_SPEC_WINDOW=10)
+    oa, ob = ea.candidate_order(), eb.candidate_order()
+    ea.reset(); eb.reset()
+    got = [[], []]
+    for q in range(max(len(oa), len(ob))):
+        for e, o, out in ((ea, oa, got[0]), (eb, ob, got[1])):
+            if q < len(o):
+                ok, info = e.agreementCheck(int(o[q]), with_info=True)
+                out.append((ok, info.lo, info.hi, info.n_cluster_loops, info.iterations, info.tries, info.flags,
+                            info.max_chi2, info.chi2_total, info.chi2_initial))
+    _assert_bitwise(ref[0], got[0])
+    _assert_bitwise(ref[1], got[1])
+
+
 def test_speculative_window_se3_is_exact():
     import bench
     g, cfg, _ = bench.build_workload("C4s")
