@@ -297,12 +297,78 @@ __device__ __forceinline__ void trsm32(double (&x)[kCB], const double* DT_generi
     }
 }
 
+// The same solve with LPR (2 or 4) adjacent lanes per row: lane q of a row's group holds the columns s * LPR + q in
+// x[s].  Column p is scaled by its owner (lane p % LPR), reaches the row's other lanes through a quad-permute DPP move
+// and is taken out of the later columns by whichever lane holds them -- per element the operations and their order are
+// those of trsm32 (x[p] * d, then x[c] -= x[p] * DT[p][c] for p ascending), so the results are the same bits; per lane it
+// is 1 / LPR of the products and of the LDS reads, on LPR times as many waves.  The next column of the block is
+// always fetched ahead (the registers are there: 32 / LPR values per lane).
+template <int LPR, int OWNER>
+__device__ __forceinline__ double trsm_bcast_from(double v)
+{
+    static_assert(LPR == 2 || LPR == 4, "two or four lanes per row");
+    constexpr int CTRL = LPR == 4 ? OWNER * 0x55 : (OWNER | (OWNER << 2) | ((2 + OWNER) << 4) | ((2 + OWNER) << 6));
+    return dpp_mov<CTRL, 0xf, 0xf>(v, v);
+}
+template <int LPR, int P>
+struct TrsmStep {
+    static constexpr int NS = kCB / LPR, SP = P / LPR, QO = P % LPR;
+    template <class DTp>
+    __device__ __forceinline__ static void run(double (&x)[NS], double (&cur)[NS], double& dpp, DTp DT, int q)
+    {
+        // the next column's entries for this lane, and its diagonal entry, before this column's products
+        double nxt[NS], dnx = 0.0;
+        if (P + 1 < kCB) {
+#pragma unroll
+            for (int s = (P + 1) / LPR; s < NS; ++s) nxt[s] = DT[(P + 1) * kCB + s * LPR + q];
+            dnx = DT[(P + 1) * kCB + (P + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double t = x[SP] * dpp;                          // (the owner's is column P; the other lanes' products are not used)
+        const double xp = trsm_bcast_from<LPR, QO>(t);
+        // slot SP: the lanes behind the owner hold later columns, the owner takes the final value, the lanes before it
+        // hold finished columns
+        if (QO + 1 < LPR) {
+            const double upd = x[SP] - xp * cur[SP];
+            x[SP] = q > QO ? upd : (q == QO ? xp : x[SP]);
+        } else {
+            x[SP] = q == QO ? xp : x[SP];
+        }
+#pragma unroll
+        for (int s = SP + 1; s < NS; ++s) x[s] -= xp * cur[s];
+        __builtin_amdgcn_sched_barrier(0);
+        if (P + 1 < kCB) {
+#pragma unroll
+            for (int s = (P + 1) / LPR; s < NS; ++s) cur[s] = nxt[s];
+            dpp = dnx;
+        }
+        if constexpr (P + 1 < kCB) TrsmStep<LPR, P + 1>::run(x, cur, dpp, DT, q);
+    }
+};
+template <int LPR>
+__device__ __forceinline__ void trsm32_lanes(double (&x)[kCB / LPR], const double* DT_generic, int q)
+{
+    constexpr int NS = kCB / LPR;
+    unsigned dt_off = (unsigned)(size_t)(lds_cdouble*)DT_generic;      // (opaque base: see trsm32)
+    asm volatile("" : "+v"(dt_off));
+    lds_cdouble* DT = (lds_cdouble*)(size_t)dt_off;
+    double cur[NS], dpp = DT[0];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cur[s] = DT[s * LPR + q];
+    TrsmStep<LPR, 0>::run(x, cur, dpp, DT, q);
+}
+
 // One 64 x 64 tile (bx >= by) of the trailing update of block column k0, by one 256-thread sub-group; the two
 // __syncthreads() are workgroup-wide, so every sub-group of the workgroup calls this the same number of times
 // (has = false: no tile this round).  DT: the factored diagonal block of the column as trsm32 reads it, in LDS.
 // skip_next_diag: leave rows / columns k1 .. k1+32 (the next diagonal block, inside tile (0, 0)) untouched.
+// after_loads(): called by every thread once the tile's loads (panel rows, old values) are on their way -- the helpers
+// write the block of the column they fetched into DT there and synchronise, so that fetch and these loads share one
+// trip to memory instead of taking two in a row.
+template <class AfterLoads>
 __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, int k0, int nb, bool has, int bx, int by,
-                                          const double* DT, double* panel, bool skip_next_diag, unsigned long long* prof)
+                                          const double* DT, double* panel, bool skip_next_diag, unsigned long long* prof,
+                                          AfterLoads after_loads)
 {
     const int t = threadIdx.x & 255, wv = t >> 6, lane = t & 63;
     const int k1 = k0 + nb;
@@ -311,23 +377,32 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
     double (*Aj)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel + kLdsPanel);
     const int tx = t & 15, ty = t >> 4;
     const unsigned long long ts0 = prof_now();
-    if (has && wv < 2) {
-        double x[kCB];
-        const int prow = wv == 0 ? i0 + lane : j0 + lane;
-        const bool pvalid = wv == 0 ? prow <= n : prow < n;           // row n (rhs) only ever is a tile ROW
-        // (address clamped instead of a predicated load: 32 loads in flight, not 32 blocks with one round trip each)
+    // panel rows of the tile: 64 of Ai and 64 of Aj, two lanes per row on the sub-group's four waves
+    constexpr int LPR = 2, NS = kCB / LPR;
+    const int pr = t >> 1, q = t & 1, lrow = pr & 63;
+    const bool first = pr < 64;
+    const int prow = first ? i0 + lrow : j0 + lrow;
+    const bool pvalid = has && (first ? prow <= n : prow < n);      // row n (rhs) only ever is a tile ROW
+    double x[NS];
+    // (address clamped instead of a predicated load: all loads in flight, not one round trip each)
 #pragma unroll
-        for (int c = 0; c < kCB; ++c) x[c] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+    for (int s2 = 0; s2 < NS; ++s2) {
+        const int c = s2 * LPR + q;
+        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+    }
+    after_loads();
+    if (has) {
 #pragma unroll
-        for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
-        double (*P)[64 + 1] = wv == 0 ? Ai : Aj;
-        trsm32<false>(x, DT, [&](int p, double v) { P[p][lane] = p < nb ? v : 0.0; });
-        // (one branch around all the stores: a conditional store per column splits the unrolled solve into 32 blocks
-        // and the register allocator gives up -- 1.5 KB of scratch per lane)
-        if (wv == 0 && by == 0 && pvalid) {
+        for (int s2 = 0; s2 < NS; ++s2) x[s2] = ((s2 * LPR + q) < nb && pvalid) ? x[s2] : 0.0;
+        trsm32_lanes<LPR>(x, DT, q);
+        double (*P)[64 + 1] = first ? Ai : Aj;
 #pragma unroll
-            for (int p = 0; p < kCB; ++p)
-                if (p < nb) st_shared(&Lf[(size_t)(k0 + p) * ld + prow], x[p]);
+        for (int s2 = 0; s2 < NS; ++s2) P[s2 * LPR + q][lrow] = (s2 * LPR + q) < nb ? x[s2] : 0.0;
+        // (one branch around all the stores of the factor: a conditional store per column splits the unrolled code)
+        if (first && by == 0 && pvalid) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+                if (s2 * LPR + q < nb) st_shared(&Lf[(size_t)(k0 + s2 * LPR + q) * ld + prow], x[s2]);
         }
     }
     __syncthreads();
@@ -416,17 +491,27 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
     for (int k0 = 0; k0 < n && alive; k0 += kCB) {
         const unsigned long long tw0 = prof_now();
         const int nb = min(kCB, n - k0), k1 = k0 + nb;
-        if (g > 0) {                                          // helpers fetch the block workgroup 0 published
-            const unsigned long long th0 = prof_now();
-            for (int idx = tid; idx < kCB * kCB; idx += kPT) {
-                const int c = idx >> 5, r = idx & 31;
+        constexpr int kDtPass = kCB * kCB / kPT;
+        double dtv[kDtPass];
+        if (g > 0) {                                          // helpers fetch the block workgroup 0 published: requested here,
+#pragma unroll                                                 // written to DT behind the first tile's own loads
+            for (int qd = 0; qd < kDtPass; ++qd) {
+                const int idx = tid + qd * kPT, c = idx >> 5, r = idx & 31;
                 const bool in = r < nb && c < nb;
-                const double v = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[(size_t)(k0 + c) * ld + k0 + r]) : &dinv[k0]);
-                DT[idx] = in ? (r >= c ? v : 0.0) : (r == c ? 1.0 : 0.0);
+                dtv[qd] = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[(size_t)(k0 + c) * ld + k0 + r]) : &dinv[k0]);
             }
-            __syncthreads();
-            prof_add1(gb.prof, kProfHelpDT, th0);
         }
+        auto write_dt = [&]() {
+            if (g > 0) {
+#pragma unroll
+                for (int qd = 0; qd < kDtPass; ++qd) {
+                    const int idx = tid + qd * kPT, c = idx >> 5, r = idx & 31;
+                    const bool in = r < nb && c < nb;
+                    DT[idx] = in ? (r >= c ? dtv[qd] : 0.0) : (r == c ? 1.0 : 0.0);
+                }
+                __syncthreads();
+            }
+        };
         const bool tiles_here = G == 1 || g > 0;
         if (tiles_here) {
             const int nti = (n + 1 - k1 + 63) / 64, ntj = max((n - k1 + 63) / 64, 1);
@@ -439,8 +524,12 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                 const bool has = tt < total;
                 int by = 0, rem = tt;
                 if (has) { while (rem >= nti - by) { rem -= nti - by; ++by; } }
-                chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
-                          G > 1 && has && by == 0 && rem == 0, gb.prof);
+                if (base == 0)
+                    chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
+                              G > 1 && has && by == 0 && rem == 0, gb.prof, write_dt);
+                else
+                    chol_tile(A, Lf, n, ld, k0, nb, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
+                              G > 1 && has && by == 0 && rem == 0, gb.prof, [] {});
             }
         }
         if (g == 0 && k1 < n) {
@@ -470,16 +559,22 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                     const bool in = idx < kTri && r < nb2;                                      // (sc <= r < nb2)
                     oldv[q] = ld_shared(&A[in ? (size_t)(k1 + es[q]) * ld + k1 + r : (size_t)0]);
                 }
-                if (tid < 64) {
-                    const int lane = tid, prow = k1 + lane;
-                    const bool pvalid = lane < nb2;
-                    double x[kCB];
+                if (tid < 128) {
+                    constexpr int LPR = 4, NS = kCB / LPR;
+                    const int lrow = tid >> 2, q = tid & 3, prow = k1 + lrow;
+                    const bool pvalid = lrow < nb2;
+                    double x[NS];
 #pragma unroll
-                    for (int c = 0; c < kCB; ++c) x[c] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        const int c = s2 * LPR + q;
+                        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+                    }
 #pragma unroll
-                    for (int c = 0; c < kCB; ++c) x[c] = (c < nb && pvalid) ? x[c] : 0.0;
+                    for (int s2 = 0; s2 < NS; ++s2) x[s2] = ((s2 * LPR + q) < nb && pvalid) ? x[s2] : 0.0;
                     prof_add(gb.prof, kProfLookLoad, tl0); tl0 = prof_now();
-                    trsm32<true>(x, DT, [&](int p, double v) { Lrow[p][lane] = p < nb ? v : 0.0; });
+                    trsm32_lanes<LPR>(x, DT, q);
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) Lrow[s2 * LPR + q][lrow] = (s2 * LPR + q) < nb ? x[s2] : 0.0;
                 }
                 // identity padding / zeros above the diagonal, then the lower triangle on top
                 for (int idx = tid; idx < kCB * kCB; idx += kPT) Dn[idx >> 5][idx & 31] = (idx >> 5) == (idx & 31) ? 1.0 : 0.0;
