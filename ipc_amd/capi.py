@@ -22,7 +22,7 @@ SYMBOLS = [
     "ipc_last_error", "ipc_create", "ipc_destroy", "ipc_set_candidates", "ipc_candidate_order",
     "ipc_initial_poses", "ipc_rows_per_rank", "ipc_solve_rows", "ipc_assemble_matrix", "ipc_set_max",
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
-    "ipc_incremental_reset", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
+    "ipc_incremental_reset", "ipc_incremental_prepare", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
     "ipc_debug_dense_solve", "ipc_append_candidate", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
 ]
@@ -100,6 +100,7 @@ def load():
     lib.ipc_solver_time_ms.argtypes = [vp, C.POINTER(dp), C.POINTER(ip)]
     lib.ipc_synchronize.argtypes = [vp]
     lib.ipc_incremental_reset.argtypes = [vp]
+    lib.ipc_incremental_prepare.argtypes = [vp]
     lib.ipc_agreement_check.argtypes = [vp, ip, C.POINTER(ip), C.POINTER(CheckInfo)]
     lib.ipc_consensus_size.argtypes = [vp, C.POINTER(ip)]
     lib.ipc_consensus_set.argtypes = [vp, vp]

@@ -20,6 +20,8 @@
 // sums, Gamma_l, loop errors) are published once per iteration with an agent-scope release / acquire pair.
 // G is sized by the capacitance system (1 for systems of one tile: then there is no cross-workgroup traffic at all).
 #pragma once
+#include <mutex>
+
 #include "cluster_se2.hpp"
 #include "cluster_se3.hpp"
 
@@ -52,7 +54,7 @@ struct PersistArgs {
     PersistCtl* ctl; PersistOut* out;
     double* dinv;                            // [n] reciprocal pivots of the factor
     unsigned long long* prof;                // optional [16] phase clocks of the leader (IPC_PERSIST_PROF=1), 100 MHz ticks
-    const int* abort_word; int launch_id;    // optional: host-mapped word; the solve gives up when it holds launch_id
+    const int* abort_word; int launch_id;    // optional: host-mapped word; the solve gives up when it has reached launch_id (ids only grow)
 };
 
 // ---- LDS carve-up (doubles) -------------------------------------------------------------------------------
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     bool lastGN = false;
     for (int it = 0; it < P.iterations && alive; ++it) {
         // a speculative solve whose starting state has been overtaken (the host committed an earlier candidate) stops here
-        if (P.abort_word && __hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == P.launch_id) { aborted = true; break; }
+        if (P.abort_word && __hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= P.launch_id) { aborted = true; break; }
         double bb, bHb, hh, bh;
         const int info = linearize(bb, bHb, hh, bh);
         if (!alive) break;
@@ -1053,9 +1055,9 @@ public:
     using Dev = typename T::Dev;
     double term_eps = 0.0;
     unsigned long long* d_prof = nullptr;       // optional device buffer [kProfN] the leader accumulates its phase clocks into
-    const int* d_abort_word = nullptr;          // optional host-mapped word (device address) and the id it is compared with
+    const int* d_abort_word = nullptr;          // optional host-mapped word (device address); the solve stops once it is >= launch_id
     int launch_id = 0;
-    int max_helpers = 39;                       // workgroups besides the leader (75 KB of LDS each)
+    int max_helpers = 39;                       // workgroups besides the leader (kLdsTotal = 141 824 bytes of LDS each: one per CU)
 
     ~PersistSolver() { release(); }
 
@@ -1091,12 +1093,23 @@ public:
         int G = 1 + std::min(max_helpers, (tiles0 + kPSG - 1) / kPSG);
         if (tiles0 == 0) G = 1;
         PersistArgs P{src, src_ld, iterations, term_eps, d_ctl_, d_out_, d_dinv_, d_prof, d_abort_word, launch_id};
-        static bool attr_set = false;
-        if (!attr_set) {
-            IPC_CL_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_persist_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kLdsTotal)));
-            attr_set = true;
-        }
+        // (once per process and kernel, whichever thread comes first: engines of ipc_run_sharded live on worker threads)
+        static std::once_flag attr_once;
+        static hipError_t attr_rc = hipSuccess;
+        static int resident_limit = 1 << 30;
+        std::call_once(attr_once, [] {
+            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_persist_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kLdsTotal));
+            // every workgroup of a launch must be resident (grid barriers): never more than the device can hold at once
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (attr_rc == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&cluster_persist_kernel<T>), kPT,
+                                                             sizeof(double) * kLdsTotal) == hipSuccess && per_cu > 0)
+                resident_limit = per_cu * prop.multiProcessorCount;
+        });
+        IPC_CL_CHK(attr_rc);
+        G = std::max(1, std::min(G, resident_limit));
         Dev D1 = D;
         T::exchange(D1);
         hipLaunchKernelGGL(cluster_persist_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P);
@@ -1120,9 +1133,13 @@ public:
         out.iterations = h_out_->iterations; out.tries = h_out_->tries; out.flags = h_out_->flags; out.evals = h_out_->evals;
         x_sel_ = h_out_->x_sel;
         aborted_ = h_out_->error == 2;
-        return h_out_->error == 1 ? hipErrorLaunchFailure : hipSuccess;
+        timed_out_ = h_out_->error == 1;
+        return hipSuccess;
     }
     bool aborted() const { return aborted_; }
+    // a grid barrier gave up (some workgroup of the launch never became resident beside foreign work on the GPU): the
+    // result is void and the caller redoes the solve with the host-driven kernels, which need no co-residency
+    bool timed_out() const { return timed_out_; }
 
     // workspaces for chains up to L poses and nl loops, up front
     hipError_t reserve(int L, int nl) { return ensure(L, nl); }
@@ -1137,7 +1154,7 @@ private:
     Dev dev_{};
     hipStream_t st_ = nullptr;
     int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
-    bool aborted_ = false;
+    bool aborted_ = false, timed_out_ = false;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
     int* d_int_ = nullptr;
     static constexpr int kTabSlots = 8;

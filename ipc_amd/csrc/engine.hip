@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <string>
 #include <chrono>
 #include <thread>
@@ -82,13 +83,11 @@ __device__ __forceinline__ void inv_sym3(const double* a, double* o)
     o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
 }
 
-// raw file records -> field-major SE2 records (robustifyVoters: info *= scale)
-__global__ void k_se2_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
-                           double unscale = 1.0)
+// raw file record -> field-major SE2 record k (robustifyVoters: info *= scale)
+__device__ __forceinline__ void se2_prep_record(const double* m, const double* inf, double scale, double unscale, double* rec,
+                                                int stride, int k)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const double tx = meas[3 * k], ty = meas[3 * k + 1], th = meas[3 * k + 2];
+    const double tx = m[0], ty = m[1], th = m[2];
     double s, c;
     sincos(th, &s, &c);
     rec[(size_t)F_TZX * stride + k] = tx;
@@ -99,12 +98,19 @@ __global__ void k_se2_prep(int n, const double* meas, const double* info, double
     double om[6], sg[6];
     // unscale != 1: the harness's final map divides the scaled information by s again
     // (reference src/simulation.cpp:55-56), i.e. (info * s) / s, not the file value
-    for (int q = 0; q < 6; ++q) om[q] = unscale == 1.0 ? info[6 * k + q] * scale : (info[6 * k + q] * scale) / unscale;
+    for (int q = 0; q < 6; ++q) om[q] = unscale == 1.0 ? inf[q] * scale : (inf[q] * scale) / unscale;
     inv_sym3(om, sg);
     for (int q = 0; q < 6; ++q) {
         rec[(size_t)(F_OM + q) * stride + k] = om[q];
         rec[(size_t)(F_SG + q) * stride + k] = sg[q];
     }
+}
+__global__ void k_se2_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
+                           double unscale = 1.0)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    se2_prep_record(meas + 3 * (size_t)k, info + 6 * (size_t)k, scale, unscale, rec, stride, k);
 }
 
 // field-major records -> record-major copy (rows beyond n stay zero)
@@ -163,24 +169,45 @@ __device__ void inv_sym6(const double* up, double* out)      // 21 upper -> 21 u
         }
 }
 
-__global__ void k_se3_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
-                           double unscale = 1.0)
+__device__ __forceinline__ void se3_prep_record(const double* m, const double* inf, double scale, double unscale, double* rec,
+                                                int stride, int k)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const double* m = meas + 7 * (size_t)k;
     const double qn = sqrt(m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + m[6] * m[6]);
     double R[9];
     R_from_quat(m[6] / qn, m[3] / qn, m[4] / qn, m[5] / qn, R);
     for (int q = 0; q < 9; ++q) rec[(size_t)(G_RZ + q) * stride + k] = R[q];
     for (int q = 0; q < 3; ++q) rec[(size_t)(G_TZ + q) * stride + k] = m[q];
     double om[21], sg[21];
-    for (int q = 0; q < 21; ++q) om[q] = unscale == 1.0 ? info[21 * (size_t)k + q] * scale : (info[21 * (size_t)k + q] * scale) / unscale;
+    for (int q = 0; q < 21; ++q) om[q] = unscale == 1.0 ? inf[q] * scale : (inf[q] * scale) / unscale;
     inv_sym6(om, sg);
     for (int q = 0; q < 21; ++q) {
         rec[(size_t)(G_OM + q) * stride + k] = om[q];
         rec[(size_t)(G_SG + q) * stride + k] = sg[q];
     }
+}
+__global__ void k_se3_prep(int n, const double* meas, const double* info, double scale, double* rec, int stride,
+                           double unscale = 1.0)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    se3_prep_record(meas + 7 * (size_t)k, info + 21 * (size_t)k, scale, unscale, rec, stride, k);
+}
+
+// ipc_append_candidate: ONE candidate record, handed over in the kernel arguments (no staging buffer, nothing to free, no
+// host synchronisation), written to slot k of the candidate arrays by the same per-record code as the batch kernels
+struct RawCandidate { double meas[7]; double info[21]; int from, to; };
+template <int DIM>
+__global__ void k_prep_one(RawCandidate r, int k, double* rec, int stride, int* from, int* to, int* lo, int* hi)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double m[7], inf[21];
+    for (int q = 0; q < 7; ++q) m[q] = r.meas[q];
+    for (int q = 0; q < 21; ++q) inf[q] = r.info[q];
+    if (DIM == 2) se2_prep_record(m, inf, 1.0, 1.0, rec, stride, k);
+    else se3_prep_record(m, inf, 1.0, 1.0, rec, stride, k);
+    from[k] = r.from; to[k] = r.to;
+    lo[k] = r.from < r.to ? r.from : r.to;
+    hi[k] = r.from < r.to ? r.to : r.from;
 }
 
 // field-major SE3 records -> blocks of 64 edges x kSe3BlkPairs double2 (se3_lds_cell.hpp reads them with
@@ -524,9 +551,12 @@ struct ipc_engine {
     double2* d_chain_blk = nullptr;                    // SE3: blocked copy [E / 64 + 2][kSe3BlkPairs][64]
     double* d_pose0 = nullptr;
     // candidates
-    double* d_cand = nullptr; int cstride = 0;
+    double* d_cand = nullptr; int cstride = 0;        // cstride = capacity in records (>= N): the list grows in place
     int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
     int* d_live = nullptr;                             // set-max: candidates with a set diagonal bit, in processing order
+    bool order_stale = false;                          // d_order is behind `order` (appends): re-sent by the next matrix-mode call
+    std::vector<void*> retired;                        // candidate arrays a growth replaced while solves in flight may still read them
+    hipEvent_t ev_cand = nullptr; bool cand_event = false;   // behind the last record written by ipc_append_candidate (own_stream)
     std::vector<int> order, h_lo, h_hi;
     std::vector<int> h_cand_ids; std::vector<double> h_cand_meas, h_cand_info;   // raw candidate records in file order
     // plan / results of the last solve
@@ -558,7 +588,7 @@ struct ipc_engine {
     bool persist = true;
     bool last_persist = false;                         // which solver holds the poses of the last cluster solve
     int* d_slot = nullptr; int slot_world = 0; int row_policy = 1;    // row -> shard slot of the last world size (IPC_ROW_BALANCE=cyclic|cost)
-    int* d_failed = nullptr; int last_lm_cells = 0;    // cells of the last solve redone with Levenberg damping
+    int* d_failed = nullptr; int failed_cap = 0; int last_lm_cells = 0;    // cells of the last solve redone with Levenberg damping
     bool lm_retry = true;                              // IPC_LM_RETRY=0: a failed linear solve ends the optimisation (flags & 2), no damping
     // Cells whose max chi2 ends within this relative distance of their threshold are solved again with g2o's literal
     // trial loop (term_eps 0): the convergence test can move an edge's chi2 by up to 2 sqrt(term_eps) relative,
@@ -566,6 +596,7 @@ struct ipc_engine {
     double borderline_band = -1.0;                     // < 0: 4 sqrt(term_eps)
     int last_literal_cells = 0;
     long lm_fallbacks = 0;
+    long persist_timeouts = 0;                         // persistent launches whose grid barrier gave up: redone by the host-driven solver
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
@@ -612,8 +643,16 @@ struct ipc_engine {
     std::vector<int> tent;                             // tentative states, by position
     std::vector<SpecResult> spec_res;                  // by processing position
     int committed_state = -1;
-    int spec_head = -1, launch_pos = 0;                // next position to hand out / to launch; head -1: pipeline empty
+    // The pipeline's PREDICTION of the caller's order: positions -> candidates.  Starts as `order` (cmpTime, ties by index);
+    // a caller that asks for another candidate than the one at the head has that candidate moved to the head (the solves
+    // behind it assumed rejects in front of them, which is still what they assume) -- the prediction costs time when it
+    // is wrong, never a decision.  Positions < spec_head are the candidates already handed out.
+    std::vector<int> porder, ppos;
+    std::vector<char> handed;                          // by candidate: its verdict has been handed to the caller since the last reset
+    int spec_head = -1;                                // next position to hand out; -1: pipeline empty
     int spec_window = 4, spec_ahead = 64;              // solves in flight / positions ahead of the head (IPC_SPEC_AHEAD)
+    bool window_forced = false;                        // IPC_SPEC_WINDOW given: taken as is, no probe
+    int stream_concurrency = 0;                        // streams of the window measured to run side by side (diagnostic)
     double accept_rate = 0.5;                          // running mean over the recent verdicts: how far ahead it pays to assume "reject"
     int helper_limit = 39;
     unsigned long long commit_count = 0;
@@ -621,7 +660,6 @@ struct ipc_engine {
     int* h_abort = nullptr;                            // host-mapped: one word per slot, the launch id to give up
     int* d_abort = nullptr;
     int next_launch_id = 1;
-    std::vector<int> pos_of;                           // candidate -> position in the processing order
     long spec_hits = 0, spec_launches = 0, spec_wasted = 0, spec_tentative = 0, spec_promoted = 0;
     double spec_t_launch = 0, spec_t_tent = 0, spec_t_total = 0;   // host seconds (IPC_SPEC_STATS)
 };
@@ -630,6 +668,7 @@ static int spec_quiesce(ipc_engine* h, bool state_changes);
 // One pipeline at a time per process: the workgroup budget of spec_pump counts this engine's solves only, and two
 // pipelines that fill the GPU between them could each end up with half-resident kernels waiting for the other's CUs.
 static ipc_engine* g_active_pipeline = nullptr;
+static std::mutex g_pipeline_mu;                       // (engines of different host threads: ipc_run_sharded, callers with one engine per thread)
 
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
@@ -734,7 +773,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         const int nq = q ? atoi(q) : 4;
         h->spec_window = nq >= 13 ? 10 : (nq >= 9 ? 8 : 4);          // (+ the engine's own stream and its two side streams)
     }
-    if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) h->spec_window = std::max(1, std::min(32, atoi(sw))); }
+    if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) { h->spec_window = std::max(1, std::min(32, atoi(sw))); h->window_forced = true; } }
     if (const char* sa = getenv("IPC_SPEC_AHEAD")) { if (*sa) h->spec_ahead = std::max(1, std::min(1024, atoi(sa))); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
@@ -813,8 +852,51 @@ static void free_candidates(ipc_engine* h)
 {
     hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order); hipFree(h->d_live);
     hipFree(h->d_slot); h->d_slot = nullptr; h->slot_world = 0;
+    for (void* q : h->retired) hipFree(q);
+    h->retired.clear();
     h->d_cand = nullptr; h->d_from = h->d_to = h->d_lo = h->d_hi = h->d_order = h->d_live = nullptr;
-    h->N = 0;
+    h->N = 0; h->cstride = 0; h->order_stale = false; h->cand_event = false;
+}
+
+// candidate arrays for `cap` records (cap a multiple of 64); the record array zeroed on own_stream
+static int alloc_candidates(ipc_engine* h, int cap)
+{
+    const int nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
+    HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * nf * (size_t)cap));
+    HIPCHK(hipMalloc(&h->d_from, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_to, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_lo, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_hi, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_order, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_live, sizeof(int) * cap));
+    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * nf * (size_t)cap, h->own_stream));
+    h->cstride = cap;
+    return IPC_OK;
+}
+
+// The list outgrew its arrays: twice the capacity, the records copied over on own_stream.  The old arrays are only
+// RETIRED (freed with the next full upload or the engine): solves in flight still read them, and hipFree would wait for
+// every one of them.  log2(N) growths over a run, 2x the final size held at most.
+static int grow_candidates(ipc_engine* h, int need)
+{
+    const int nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
+    int cap = std::max(64, h->cstride);
+    while (cap < need) cap *= 2;
+    double* o_cand = h->d_cand; const int o_stride = h->cstride;
+    int *o_from = h->d_from, *o_to = h->d_to, *o_lo = h->d_lo, *o_hi = h->d_hi, *o_order = h->d_order, *o_live = h->d_live;
+    if (int rc = alloc_candidates(h, cap)) return rc;
+    if (h->N > 0) {
+        HIPCHK(hipMemcpy2DAsync(h->d_cand, sizeof(double) * cap, o_cand, sizeof(double) * o_stride, sizeof(double) * h->N, nf,
+                                hipMemcpyDeviceToDevice, h->own_stream));
+        HIPCHK(hipMemcpyAsync(h->d_from, o_from, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
+        HIPCHK(hipMemcpyAsync(h->d_to, o_to, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
+        HIPCHK(hipMemcpyAsync(h->d_lo, o_lo, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
+        HIPCHK(hipMemcpyAsync(h->d_hi, o_hi, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
+    }
+    for (void* q : {(void*)o_cand, (void*)o_from, (void*)o_to, (void*)o_lo, (void*)o_hi, (void*)o_order, (void*)o_live})
+        if (q) h->retired.push_back(q);
+    h->order_stale = true;
+    return IPC_OK;
 }
 
 extern "C" int ipc_destroy(ipc_engine_t* h)
@@ -822,7 +904,10 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
     spec_quiesce(h, true);
-    if (g_active_pipeline == h) g_active_pipeline = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pipeline_mu);
+        if (g_active_pipeline == h) g_active_pipeline = nullptr;
+    }
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
@@ -854,10 +939,10 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         if (stt.ready) hipEventDestroy(stt.ready);
     }
     if (h->d_prof || getenv("IPC_SPEC_STATS"))
-        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
+        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"streams_abreast\": %d, \"persist_timeouts\": %ld, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
                         "\"tentative_states\": %ld, \"promoted\": %ld, \"host_s_in_checks\": %.3f, \"host_s_launching\": %.3f, "
                         "\"host_s_tentative\": %.3f}}\n",
-                h->spec_window, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
+                h->spec_window, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
                 h->spec_t_total, h->spec_t_launch, h->spec_t_tent);
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
     if (h->h_abort) hipHostFree(h->h_abort);
@@ -876,9 +961,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     return IPC_OK;
 }
 
-// Uploads the candidate list (file order).  preserve_state: the list only GREW at its end (ipc_append_candidate), so the
-// consensus set (candidate indices) and the current poses stay what they are; otherwise the incremental state is reset.
-static int upload_candidates(ipc_engine* h, int n, const int* ids, const double* meas, const double* info, bool preserve_state)
+// Uploads the candidate list (file order); the consensus set and the current poses go back to the open-loop state.
+static int upload_candidates(ipc_engine* h, int n, const int* ids, const double* meas, const double* info)
 {
     for (int k = 0; k < n; ++k) {
         const int f = ids[2 * k], t = ids[2 * k + 1];
@@ -893,44 +977,31 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     free_candidates(h);
     h->last_cells = 0;
     h->ev_valid = false;
-    if (!preserve_state) {
-        h->cns.clear();
-        if (h->d_cur && h->d_open)
-            HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
-    }
-    h->h_from.clear(); h->h_to.clear();
-    {   // host copy of the raw records (ipc_append_candidate re-uploads the grown list)
-        const int ms_ = h->dim == 2 ? 3 : 7, is_ = h->dim == 2 ? 6 : 21;
-        std::vector<int> ci(ids, ids + 2 * (size_t)n);
-        std::vector<double> cm(meas, meas + (size_t)ms_ * n), cinf(info, info + (size_t)is_ * n);
-        h->h_cand_ids.swap(ci); h->h_cand_meas.swap(cm); h->h_cand_info.swap(cinf);
-    }
-    if (n == 0) { h->order.clear(); h->h_lo.clear(); h->h_hi.clear(); return IPC_OK; }
-    std::vector<int> from(n), to(n);
-    h->h_lo.resize(n); h->h_hi.resize(n);
+    h->cns.clear();
+    if (h->d_cur && h->d_open)
+        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
+    const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
+    h->h_cand_ids.assign(ids, ids + 2 * (size_t)n);                       // raw records (row assignment, appends)
+    h->h_cand_meas.assign(meas, meas + (size_t)ms * n);
+    h->h_cand_info.assign(info, info + (size_t)is * n);
+    h->h_from.resize(n); h->h_to.resize(n); h->h_lo.resize(n); h->h_hi.resize(n);
     for (int k = 0; k < n; ++k) {
-        from[k] = ids[2 * k]; to[k] = ids[2 * k + 1];
-        h->h_lo[k] = std::min(from[k], to[k]); h->h_hi[k] = std::max(from[k], to[k]);
+        h->h_from[k] = ids[2 * k]; h->h_to[k] = ids[2 * k + 1];
+        h->h_lo[k] = std::min(h->h_from[k], h->h_to[k]); h->h_hi[k] = std::max(h->h_from[k], h->h_to[k]);
     }
     // cmpTime order (src/utils.cpp:379-390) with the (max id, index) tie-break
     h->order.resize(n);
     std::iota(h->order.begin(), h->order.end(), 0);
     std::stable_sort(h->order.begin(), h->order.end(), [&](int a, int b) { return h->h_hi[a] < h->h_hi[b]; });
+    h->porder = h->order;
+    h->handed.assign(n, 0);
+    h->ppos.assign(n, 0);
+    for (int q = 0; q < n; ++q) h->ppos[h->porder[q]] = q;
+    if (n == 0) return IPC_OK;
+    if (int rc = alloc_candidates(h, (n + 63) & ~63)) return rc;
     h->N = n;
-    h->pos_of.assign(n, 0);
-    for (int q = 0; q < n; ++q) h->pos_of[h->order[q]] = q;
-    h->h_from = from; h->h_to = to;
-    h->cstride = (n + 63) & ~63;
-    const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21, nf = h->dim == 2 ? (int)F_NFIELDS : (int)G_NFIELDS;
-    HIPCHK(hipMalloc(&h->d_cand, sizeof(double) * nf * h->cstride));
-    HIPCHK(hipMalloc(&h->d_from, sizeof(int) * n));
-    HIPCHK(hipMalloc(&h->d_to, sizeof(int) * n));
-    HIPCHK(hipMalloc(&h->d_lo, sizeof(int) * n));
-    HIPCHK(hipMalloc(&h->d_hi, sizeof(int) * n));
-    HIPCHK(hipMalloc(&h->d_order, sizeof(int) * n));
-    HIPCHK(hipMalloc(&h->d_live, sizeof(int) * n));
-    HIPCHK(hipMemcpy(h->d_from, from.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_to, to.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_from, h->h_from.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_to, h->h_to.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_lo, h->h_lo.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_hi, h->h_hi.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_order, h->order.data(), sizeof(int) * n, hipMemcpyHostToDevice));
@@ -939,7 +1010,6 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * n));
     HIPCHK(hipMemcpy(d_m, meas, sizeof(double) * ms * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_i, info, sizeof(double) * is * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * nf * h->cstride, h->own_stream));
     if (h->dim == 2)
         hipLaunchKernelGGL(k_se2_prep, dim3((n + 255) / 256), dim3(256), 0, h->own_stream, n, d_m, d_i, 1.0,
                            h->d_cand, h->cstride);
@@ -957,21 +1027,73 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_set_candidates: NULL handle");
     if (n < 0 || (n > 0 && (!ids || !meas || !info))) return fail(IPC_ERR_ARG, "ipc_set_candidates: bad arrays");
-    return upload_candidates(h, n, ids, meas, info, false);
+    return upload_candidates(h, n, ids, meas, info);
 }
 
+static void spec_insert_position(ipc_engine* h, int k);
+static void spec_move_to_head(ipc_engine* h, int k);
+
+// One more candidate at the end of the list (the harness hands IPC::agreementCheck an edge nobody announced,
+// reference src/simulation.cpp:34-47).  The consensus set, the poses and whatever the pipeline has in flight stay as they
+// are: one record is written in place by a one-thread kernel that carries it in its arguments -- no re-upload, no
+// allocation (the arrays grow geometrically), no hipFree, no host synchronisation.
 extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const double* meas, const double* info, int* index_out)
 {
     if (!h || !ids || !meas || !info) return fail(IPC_ERR_ARG, "ipc_append_candidate: NULL argument");
     const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
-    std::vector<int> ci = h->h_cand_ids;
-    std::vector<double> cm = h->h_cand_meas, cinf = h->h_cand_info;
-    const int n = (int)ci.size() / 2;
-    ci.insert(ci.end(), ids, ids + 2);
-    cm.insert(cm.end(), meas, meas + ms);
-    cinf.insert(cinf.end(), info, info + is);
-    if (int rc = upload_candidates(h, n + 1, ci.data(), cm.data(), cinf.data(), true)) return rc;
-    if (index_out) *index_out = n;
+    const int f = ids[0], t = ids[1], k = h->N;
+    if (f < 0 || t < 0 || f >= h->V || t >= h->V)
+        return fail(IPC_ERR_ARG, "candidate %d joins vertex %d-%d outside 0..%d", k, f, t, h->V - 1);
+    if (std::abs(f - t) < 2)
+        return fail(IPC_ERR_ARG, "candidate %d joins adjacent vertices %d-%d (an odometry edge, reference src/utils.cpp:184)", k, f, t);
+    HIPCHK(hipSetDevice(h->device));
+    if (k + 1 > h->cstride) { if (int rc = grow_candidates(h, k + 1)) return rc; }
+    if (!h->ev_cand) HIPCHK(hipEventCreateWithFlags(&h->ev_cand, hipEventDisableTiming));
+    RawCandidate r{};
+    for (int q = 0; q < ms; ++q) r.meas[q] = meas[q];
+    for (int q = 0; q < is; ++q) r.info[q] = info[q];
+    r.from = f; r.to = t;
+    if (h->dim == 2)
+        hipLaunchKernelGGL(k_prep_one<2>, dim3(1), dim3(64), 0, h->own_stream, r, k, h->d_cand, h->cstride, h->d_from, h->d_to, h->d_lo, h->d_hi);
+    else
+        hipLaunchKernelGGL(k_prep_one<3>, dim3(1), dim3(64), 0, h->own_stream, r, k, h->d_cand, h->cstride, h->d_from, h->d_to, h->d_lo, h->d_hi);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_cand, h->own_stream));                   // (what the pipeline's streams wait for before a launch)
+    h->cand_event = true;
+    h->h_cand_ids.insert(h->h_cand_ids.end(), ids, ids + 2);
+    h->h_cand_meas.insert(h->h_cand_meas.end(), meas, meas + ms);
+    h->h_cand_info.insert(h->h_cand_info.end(), info, info + is);
+    h->h_from.push_back(f); h->h_to.push_back(t);
+    h->h_lo.push_back(std::min(f, t)); h->h_hi.push_back(std::max(f, t));
+    // (max id, index): behind every candidate that ends at or before its later vertex
+    const int hi = h->h_hi[k];
+    const auto it = std::upper_bound(h->order.begin(), h->order.end(), hi, [&](int v, int c) { return v < h->h_hi[c]; });
+    h->order.insert(it, k);
+    h->N = k + 1;
+    h->order_stale = true;
+    h->last_cells = 0;                                   // the cells of the last matrix solve are those of the shorter list
+    h->ev_valid = false;
+    if (h->d_slot) { h->retired.push_back(h->d_slot); h->d_slot = nullptr; }
+    h->slot_world = 0;
+    spec_insert_position(h, k);
+    if (index_out) *index_out = k;
+    return IPC_OK;
+}
+
+// Entry of every matrix-mode call that launches on `st`.  (i) The pipeline of the faithful mode must not be on the GPU
+// beside the cell kernels: its persistent launches meet at grid barriers and need all their workgroups resident, which a
+// full machine does not grant -- whatever it has in flight is given up (it restarts with the next
+// ipc_agreement_check).  (ii) Records appended since the last call were written on own_stream: `st` waits for them, and
+// the processing order on the device is brought up to date.
+static int matrix_mode_enter(ipc_engine* h, hipStream_t st)
+{
+    if (!h->slots.empty() && h->spec_head >= 0) { if (int rc = spec_quiesce(h, true)) return rc; }
+    if (h->order_stale && h->N > 0) {
+        HIPCHK(hipMemcpyAsync(h->d_order, h->order.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->own_stream));
+        HIPCHK(hipStreamSynchronize(h->own_stream));     // (pageable source: the copy has left the host vector when this returns)
+        h->order_stale = false;
+    }
+    if (h->cand_event && st != h->own_stream) HIPCHK(hipStreamWaitEvent(st, h->ev_cand, 0));
     return IPC_OK;
 }
 
@@ -1047,14 +1169,18 @@ static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src,
             IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
                                            h->h_from.data(), h->h_to.data(), iters));
             IPC_CL_CHK(h->persist3->wait(o));
+            if (h->persist3->timed_out()) { o.flags |= 2; ++h->persist_timeouts; }
         } else {
             IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
                                            h->h_from.data(), h->h_to.data(), iters));
             IPC_CL_CHK(h->persist2->wait(o));
+            if (h->persist2->timed_out()) { o.flags |= 2; ++h->persist_timeouts; }
         }
+        // (a barrier that timed out -- workgroups not resident beside foreign work -- takes the same way out: redone below)
         // a non-positive pivot in the capacitance factorisation: g2o would retry with Levenberg damping -- the
         // host-driven solver does (dense normal equations), from the same start
-        if (!(o.flags & 2) || !h->lm_retry) return hipSuccess;
+        const bool lost = h->dim == 3 ? h->persist3->timed_out() : h->persist2->timed_out();
+        if (!lost && (!(o.flags & 2) || !h->lm_retry)) return hipSuccess;
         h->last_persist = false;
         ++h->lm_fallbacks;
     }
@@ -1146,8 +1272,14 @@ __global__ void k_collect_failed(int ncells, const int4* meta, const double* chi
 }
 static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
 {
-    constexpr int kCap = 16384;
-    if (!h->d_failed) HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * (kCap + 1)));
+    // (the list can hold every cell: IPC_BORDERLINE_BAND up to 0.5 may select most of them, and none may be dropped silently)
+    if (total > h->failed_cap) {
+        HIPCHK(hipFree(h->d_failed));
+        h->d_failed = nullptr;
+        h->failed_cap = std::max(16384, total + total / 8);
+        HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * ((size_t)h->failed_cap + 1)));
+    }
+    const int kCap = h->failed_cap;
     HIPCHK(hipMemsetAsync(h->d_failed + kCap, 0, sizeof(int), st));
     const double band = h->term_eps > 0 ? (h->borderline_band >= 0 ? h->borderline_band : 4.0 * std::sqrt(h->term_eps)) : 0.0;
     hipLaunchKernelGGL(k_collect_failed, dim3((total + 255) / 256), dim3(256), 0, st, total, (const int4*)h->d_meta,
@@ -1211,6 +1343,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
+    if (int rc = matrix_mode_enter(h, st)) return rc;
     if (int rc = ensure_row_map(h, world)) return rc;
     const BinCaps bc = h->plan.caps;
     const int nb = bc.n;
@@ -1339,6 +1472,7 @@ extern "C" int ipc_assemble_matrix(ipc_engine_t* h, const uint64_t* d_gathered, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
     const int N = h->N, words = (N + 63) / 64, rpr = ipc_rows_per_rank(N, world);
+    if (int rc = matrix_mode_enter(h, st)) return rc;
     if (int rc = ensure_row_map(h, world)) return rc;
     hipLaunchKernelGGL(k_assemble, dim3(words, std::min((N + 255) / 256, 1024)), dim3(256), 0, st, N, words, (const int*)h->d_slot, h->d_lo,
                        h->d_hi, (const unsigned long long*)d_gathered, (unsigned long long*)d_bits);
@@ -1355,6 +1489,7 @@ extern "C" int ipc_set_max(ipc_engine_t* h, const uint64_t* d_bits, uint8_t* d_a
     const int N = h->N, words = (N + 63) / 64;
     const size_t shmem = sizeof(unsigned long long) * words;
     if (shmem > 60 * 1024) return fail(IPC_ERR_LIMIT, "ipc_set_max: N=%d exceeds the LDS-resident mask", N);
+    if (int rc = matrix_mode_enter(h, st)) return rc;
     hipLaunchKernelGGL(k_set_max, dim3(1), dim3(1024), shmem, st, N, words, h->d_order,
                        (const unsigned long long*)d_bits, d_accepted, h->d_live);
     HIPCHK(hipGetLastError());
@@ -1639,6 +1774,15 @@ static void fill_info(ipc_check_info_t* info, int lo, int hi, int nloops, const 
     info->max_chi2 = o.max_chi2; info->chi2_total = o.chi2_total; info->chi2_initial = o.chi2_initial;
 }
 
+static int spec_ensure(ipc_engine* h);
+extern "C" int ipc_incremental_prepare(ipc_engine_t* h)
+{
+    if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_prepare: NULL handle");
+    if (int rc = ensure_incremental(h, "ipc_incremental_prepare")) return rc;
+    if (h->persist && h->spec_window > 1) { if (int rc = spec_ensure(h)) return rc; }
+    return IPC_OK;
+}
+
 extern "C" int ipc_incremental_reset(ipc_engine_t* h)
 {
     if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_reset: NULL handle");
@@ -1646,6 +1790,9 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
     if (int rc = spec_quiesce(h, true)) return rc;
     HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
     h->cns.clear();
+    std::fill(h->handed.begin(), h->handed.end(), 0);
+    h->porder = h->order;
+    for (int q = 0; q < h->N; ++q) h->ppos[h->porder[q]] = q;
     return IPC_OK;
 }
 
@@ -1705,6 +1852,32 @@ static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, c
 }
 
 // ---- speculative candidate pipeline (see ipc_engine::SpecSlot) ---------------------------------------------
+__global__ void k_nap(unsigned long long ticks)             // (100 MHz wall clock)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// How many of `n` streams really run side by side: streams that share a hardware queue run their kernels one after the
+// other, and how many queues the runtime has was decided at ITS initialisation (GPU_MAX_HW_QUEUES), which this library
+// may or may not have been in time for.  One 200 us nap per stream, all at once: the wall time says how many ran abreast.
+static int probe_stream_concurrency(hipStream_t* st, int n)
+{
+    if (n <= 1) return n;
+    const unsigned long long nap = 20000;                  // 200 us
+    for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k_nap, dim3(1), dim3(64), 0, st[q], 100ull);    // (code object loaded, queues created)
+    for (int q = 0; q < n; ++q) if (hipStreamSynchronize(st[q]) != hipSuccess) return 1;
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k_nap, dim3(1), dim3(64), 0, st[q], nap);
+        for (int q = 0; q < n; ++q) if (hipStreamSynchronize(st[q]) != hipSuccess) return 1;
+        best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    const double rounds = std::max(1.0, best / 200e-6 - 0.35);             // (launch + sync overhead of the probe itself)
+    return std::max(1, std::min(n, (int)std::lround(n / rounds)));
+}
+
 static int spec_ensure(ipc_engine* h)
 {
     if (!h->slots.empty()) return IPC_OK;
@@ -1723,12 +1896,21 @@ static int spec_ensure(ipc_engine* h)
         if (h->dim == 3) {
             sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s3->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s3->reserve(h->V - 1, std::min(h->N, 256)));
+            HIPCHK(sl.s3->reserve(h->V - 1, 256));
         } else {
             sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s2->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s2->reserve(h->V - 1, std::min(h->N, 256)));
+            HIPCHK(sl.s2->reserve(h->V - 1, 256));
         }
+    }
+    if (!h->window_forced) {
+        hipStream_t sts[64];
+        const int n = std::min((int)h->slots.size(), 64);
+        for (int q = 0; q < n; ++q) sts[q] = h->slots[q].st;
+        // Reported with IPC_SPEC_STATS, not acted on: capping the solves in flight at the measured figure was tried and
+        // LOSES (C2: 6 abreast measured, 588 candidates/s capped at 6 against 827 with all 10 in flight -- a solve queued
+        // behind another on its hardware queue still starts the moment that one ends, without a host round trip)
+        h->stream_concurrency = probe_stream_concurrency(sts, n);
     }
     return IPC_OK;
 }
@@ -1790,7 +1972,6 @@ static void spec_drop_after(ipc_engine* h, int p)
         h->spec_states[h->tent.back()].live = false;
         h->tent.pop_back();
     }
-    h->launch_pos = std::min(h->launch_pos, p + 1);
 }
 
 // the committed state as an object of the pipeline: the current poses (d_cur) and the current set
@@ -1821,12 +2002,15 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers)
 {
     SpecTimer tm(h->spec_t_launch);
     ipc_engine::SpecSlot& sl = h->slots[q];
-    const int k = h->order[p], si = spec_state_at(h, p);
+    const int k = h->porder[p], si = spec_state_at(h, p);
     ipc_engine::SpecState& S = h->spec_states[si];
+    if (h->cand_event) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_cand, 0));  // (records ipc_append_candidate wrote on own_stream)
     const ClusterSpec c = cluster_of(h, k, S.cns);
     sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th;
+    // (ids only grow, per slot too: the kernels give up when their slot's word has reached their id, so an abort also
+    // reaches a launch that was still queued behind another aborted one when the word moved on)
     sl.launch_id = h->next_launch_id++;
-    if (h->next_launch_id == 0x7fffffff) h->next_launch_id = 1;
+    if (h->next_launch_id >= 0x7ffffff0) return fail(IPC_ERR_LIMIT, "ipc_agreement_check: 2^31 solves launched on one engine");
     if (S.has_ready) HIPCHK(hipStreamWaitEvent(sl.st, S.ready, 0));
     else if (!S.owned && h->commit_count) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
     ++S.users;
@@ -1871,13 +2055,89 @@ static int spec_make_tentative(ipc_engine* h, int p, int q)
     HIPCHK(hipEventRecord(T.ready, sl.st));
     T.has_ready = true;
     T.cns = P.cns;
-    T.cns.push_back(h->order[p]);
+    T.cns.push_back(h->porder[p]);
     T.pos = p;
     h->tent.push_back(t);
     R.child = t;
-    h->launch_pos = p + 1;
     ++h->spec_tentative;
     return IPC_OK;
+}
+
+// moves the candidate at position `from` to position `to` of the prediction; everything keyed by position follows
+static void spec_move_position(ipc_engine* h, int from, int to)
+{
+    if (from == to) return;
+    auto remap = [&](int q) {
+        if (q == from) return to;
+        if (from > to) return (q >= to && q < from) ? q + 1 : q;
+        return (q > from && q <= to) ? q - 1 : q;
+    };
+    if (from > to) {
+        std::rotate(h->porder.begin() + to, h->porder.begin() + from, h->porder.begin() + from + 1);
+        std::rotate(h->spec_res.begin() + to, h->spec_res.begin() + from, h->spec_res.begin() + from + 1);
+    } else {
+        std::rotate(h->porder.begin() + from, h->porder.begin() + from + 1, h->porder.begin() + to + 1);
+        std::rotate(h->spec_res.begin() + from, h->spec_res.begin() + from + 1, h->spec_res.begin() + to + 1);
+    }
+    for (int q = std::min(from, to); q <= std::max(from, to); ++q) h->ppos[h->porder[q]] = q;
+    for (auto& sl : h->slots) if (sl.cand >= 0) sl.pos = remap(sl.pos);
+    for (int t : h->tent) h->spec_states[t].pos = remap(h->spec_states[t].pos);
+    std::sort(h->tent.begin(), h->tent.end(), [&](int a, int b) { return h->spec_states[a].pos < h->spec_states[b].pos; });
+}
+
+// The caller asks for candidate k, which the prediction has elsewhere than at the head.  k moves to the head.  Every solve
+// in flight and every parked result assumed that the candidates in front of it reject (or built on a tentative accept in
+// front of it) -- with k in front of them that is still all they assume, so they stay; k's own work survives only if it
+// started from the committed state, and what was built on a tentative accept of k goes.
+static void spec_move_to_head(ipc_engine* h, int k)
+{
+    const int p = h->ppos[k], head = h->spec_head;
+    if (p < head) {                                    // handed out before (a re-check): back in front of the head, nothing of it is in flight
+        spec_move_position(h, p, head - 1);
+        h->spec_head = head - 1;
+        h->spec_res[h->spec_head] = ipc_engine::SpecResult{};
+        return;
+    }
+    ipc_engine::SpecResult& R = h->spec_res[p];
+    const bool from_committed = spec_state_at(h, p) == h->committed_state;
+    if (R.valid && R.agree && R.child >= 0) {
+        // k's accept is already a tentative state.  From the committed state: it stays and everything else in flight is
+        // redone on top of it; otherwise it goes with everything behind it.
+        if (from_committed) {
+            spec_move_position(h, p, head);
+            spec_drop_after(h, head);
+            return;
+        }
+        spec_drop_after(h, p - 1);
+    } else if (!from_committed) {
+        if (R.valid) { R.valid = false; ++h->spec_wasted; }
+        for (size_t q = 0; q < h->slots.size(); ++q)
+            if (h->slots[q].cand >= 0 && h->slots[q].pos == p) spec_abort_slot(h, (int)q);
+    }
+    spec_move_position(h, p, head);
+}
+
+// ipc_append_candidate while the pipeline is up: candidate k (the last index) gets a position in the prediction -- behind
+// the not yet handed out candidates that end at or before its later vertex (cmpTime) -- and everything behind it shifts
+static void spec_insert_position(ipc_engine* h, int k)
+{
+    const int n = (int)h->porder.size();               // == k
+    int q = n;
+    if (h->spec_head >= 0) {
+        q = std::max(h->spec_head, 0);
+        while (q < n && h->h_hi[h->porder[q]] <= h->h_hi[k]) ++q;
+    } else {
+        while (q > 0 && h->h_hi[h->porder[q - 1]] > h->h_hi[k]) --q;
+    }
+    h->porder.push_back(k);
+    h->ppos.push_back(n);
+    h->handed.push_back(0);
+    if (h->spec_head >= 0) h->spec_res.emplace_back();
+    if (h->spec_head >= 0) spec_move_position(h, n, q);
+    else {
+        std::rotate(h->porder.begin() + q, h->porder.begin() + n, h->porder.end());
+        for (int i = q; i <= n; ++i) h->ppos[h->porder[i]] = i;
+    }
 }
 
 // One turn of the pipeline: collect the solves that have ended, let the accepts among them (earliest first) move the
@@ -1897,6 +2157,8 @@ static int spec_pump(ipc_engine* h)
         ClusterOut o;
         HIPCHK(h->dim == 3 ? sl.s3->fetch(o) : sl.s2->fetch(o));
         const bool aborted = h->dim == 3 ? sl.s3->aborted() : sl.s2->aborted();
+        const bool lost = h->dim == 3 ? sl.s3->timed_out() : sl.s2->timed_out();
+        if (lost) ++h->persist_timeouts;
         const int p = sl.pos;
         --h->spec_states[sl.state].users;
         const bool stale = aborted || p < h->spec_head || sl.state != spec_state_at(h, p);
@@ -1905,7 +2167,7 @@ static int spec_pump(ipc_engine* h)
         ipc_engine::SpecResult& R = h->spec_res[p];
         R = ipc_engine::SpecResult{};
         R.valid = true; R.state = sl.state; R.lo = sl.lo; R.hi = sl.hi; R.nclu = sl.nclu; R.o = o;
-        R.retry_host = (o.flags & 2) && h->lm_retry;                          // (decided when its turn comes, by the damped solver)
+        R.retry_host = lost || ((o.flags & 2) && h->lm_retry);                // (decided when its turn comes, by the host-driven solver)
         R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
         fin_pos[nfin] = p; fin_slot[nfin] = q; ++nfin;
     }
@@ -1922,14 +2184,20 @@ static int spec_pump(ipc_engine* h)
     int target = B;
     if (h->accept_rate > 0.01) {
         const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
-        target = std::max(2, std::min(B, 1 + (int)r));
+        target = std::max(2, std::min(target, 1 + (int)r));
     }
-    while (h->launch_pos < h->N && h->launch_pos - h->spec_head < h->spec_ahead) {
+    // the positions to launch: lowest first, the ones from the head on that have neither a parked result nor a solve in flight
+    const int end = std::min(h->N, h->spec_head + h->spec_ahead);
+    for (int lp = h->spec_head; lp < end; ++lp) {
+        if (h->spec_res[lp].valid) continue;
         int q = -1, running = 0, busy = 0;
+        bool in_flight = false;
         for (int i = 0; i < B; ++i) {
             running += h->slots[i].cand >= 0;
+            in_flight = in_flight || (h->slots[i].cand >= 0 && h->slots[i].pos == lp);
             if (h->slots[i].cand < 0 && (q < 0 || (h->slots[q].busy_wgs && !h->slots[i].busy_wgs))) q = i;   // (an empty stream first)
         }
+        if (in_flight) continue;
         if (q < 0 || running >= target) break;
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
@@ -1937,10 +2205,9 @@ static int spec_pump(ipc_engine* h)
         for (int i = 0; i < B; ++i) if (i != q) busy += h->slots[i].busy_wgs;
         const int helpers = std::min(h->helper_limit, h->n_cu - 8 - busy - 1);
         if (helpers < std::min(8, h->helper_limit) && running > 0) break;                     // (wait for a solve to leave)
-        const int tip = spec_state_at(h, h->launch_pos);
+        const int tip = spec_state_at(h, lp);
         if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) break;
-        if (int rc = spec_launch(h, q, h->launch_pos, std::max(0, helpers))) return rc;
-        ++h->launch_pos;
+        if (int rc = spec_launch(h, q, lp, std::max(0, helpers))) return rc;
     }
     return IPC_OK;
 }
@@ -1962,22 +2229,28 @@ static int spec_reset(ipc_engine* h)
 static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
 {
     if (int rc = spec_ensure(h)) return rc;
-    if (g_active_pipeline && g_active_pipeline != h) {
-        HIPCHK(hipSetDevice(g_active_pipeline->device));
-        const int rc = spec_reset(g_active_pipeline);
-        HIPCHK(hipSetDevice(h->device));
-        if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_pipeline_mu);
+        if (g_active_pipeline && g_active_pipeline != h) {
+            HIPCHK(hipSetDevice(g_active_pipeline->device));
+            const int rc = spec_reset(g_active_pipeline);
+            HIPCHK(hipSetDevice(h->device));
+            if (rc) return rc;
+        }
+        g_active_pipeline = h;
     }
-    g_active_pipeline = h;
     SpecTimer tm(h->spec_t_total);
-    const int p = h->pos_of[k];
-    if (h->spec_head != p) {                           // first call, or a caller off the processing order: start over at k
+    if (h->spec_head < 0) {                            // first call (or after a reset): the pipeline starts from the poses as they are
         if (int rc = spec_reset(h)) return rc;
         if (int rc = spec_adopt_current(h)) return rc;
         h->spec_res.assign(h->N, ipc_engine::SpecResult{});
-        h->spec_head = p;
-        h->launch_pos = p;
+        // the candidates already handed out in front of the head, the others behind it, both in the order they have
+        std::stable_partition(h->porder.begin(), h->porder.end(), [&](int c) { return h->handed[c] != 0; });
+        h->spec_head = 0;
+        for (int q = 0; q < h->N; ++q) { h->ppos[h->porder[q]] = q; h->spec_head += h->handed[h->porder[q]] != 0; }
     }
+    if (h->ppos[k] != h->spec_head) spec_move_to_head(h, k);          // a caller off the predicted order
+    const int p = h->spec_head;
     for (unsigned spin = 0;; ++spin) {
         if (int rc = spec_pump(h)) return rc;
         if (h->spec_res[p].valid) break;
@@ -2011,6 +2284,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
             HIPCHK(hipEventRecord(h->ev_commit, h->own_stream));
             ++h->commit_count;
         }
+        h->handed[k] = 1;
         // (spec_head is -1: the next call starts the pipeline again from the poses as they are now)
     } else {
         if (agree) {                                                          // :69-71 -- the tentative state becomes THE state
@@ -2030,6 +2304,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
             ++h->spec_promoted;
         }
         h->spec_head = p + 1;
+        h->handed[k] = 1;
         h->accept_rate += 0.08 * ((agree ? 1.0 : 0.0) - h->accept_rate);
         if (h->spec_head >= h->N) { if (int rc = spec_reset(h)) return rc; }
     }
@@ -2071,6 +2346,7 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
         }
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
+    h->handed[k] = 1;
     *agrees = agree ? 1 : 0;
     fill_info(info, c.lo, c.hi, c.nclu, o);
     return IPC_OK;

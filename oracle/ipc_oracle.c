@@ -756,20 +756,25 @@ double oracle_pair_cell(int dim, const double *odom_meas, const double *odom_inf
                              lid, lm, li, slow_iter, NULL, NULL, stats);
 }
 
-/* Batch of pair cells over a static partition of the list across POSIX threads (thread t takes cells
- * t, t + T, t + 2T, ...): the all-core CPU baseline SURVEY.md 8(d) asks for (the reference itself is
- * single-threaded; its only concurrency is independent processes, bash/ipc_experiments_2D.sh:34).
+/* Batch of pair cells over POSIX threads that draw cells from one shared queue (an atomic counter over the
+ * list, in list order: callers put the expensive cells first): the all-core CPU baseline SURVEY.md 8(d) asks
+ * for (the reference itself is single-threaded; its only concurrency is independent processes,
+ * bash/ipc_experiments_2D.sh:34).  A static partition left the run waiting for whichever thread drew a cell
+ * that runs to the iteration cap (round 3: 10x scaling on 256 threads).
  * max_chi2_out / iterations_out have n entries.  Returns the number of threads actually started. */
 #include <pthread.h>
 typedef struct {
     int dim; const double *odom_meas, *odom_info; double s_factor; const double *poses; const int *ids;
     const double *meas, *info; int fast_iter, slow_iter; int n; const int *ci, *cj; double *mx; int *its;
-    int t, T;
+    int t, T; int *next;
 } mt_job_t;
 static void *mt_worker(void *arg)
 {
     mt_job_t *q = (mt_job_t *)arg;
-    for (int k = q->t; k < q->n; k += q->T) {
+    if (q->T == 0) return NULL;
+    for (;;) {
+        const int k = __atomic_fetch_add(q->next, 1, __ATOMIC_RELAXED);
+        if (k >= q->n) break;
         int solved;
         oracle_stats_t st;
         memset(&st, 0, sizeof st);
@@ -789,10 +794,10 @@ int oracle_pair_cells_mt(int dim, const double *odom_meas, const double *odom_in
     if (nthreads > 1024) nthreads = 1024;
     mt_job_t *jobs = (mt_job_t *)malloc(sizeof(mt_job_t) * (size_t)nthreads);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-    int started = 0;
+    int started = 0, next = 0;
     for (int t = 0; t < nthreads; ++t) {
         mt_job_t j = { dim, odom_meas, odom_info, s_factor, poses, ids, meas, info, fast_iter, slow_iter, n, ci, cj,
-                       max_chi2_out, iterations_out, t, nthreads };
+                       max_chi2_out, iterations_out, t, nthreads, &next };
         jobs[t] = j;
     }
     for (int t = 1; t < nthreads; ++t)
