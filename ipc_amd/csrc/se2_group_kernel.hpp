@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_group_kernel(Se2Vi
         unsigned c = 0;
         if (wsub == 0 && lane == 0) {
             c = atomicAdd(counter, 1u);
-            box->data[0][seq & 1][0] = (double)c;
+            mb_store(&box->data[0][seq & 1][0], (double)c);
         }
         wave_sync();
         if (lane == 0) __hip_atomic_store(&box->flag[wsub], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 1) void se2_group_kernel(Se2Vi
                 IPC_SPIN_WAIT();
         }
         wave_sync();
-        c = (unsigned)box->data[0][seq & 1][0];
+        c = (unsigned)mb_load(&box->data[0][seq & 1][0]);
         c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
         if (c >= (unsigned)ncells) break;
         const int2 cc = cells[c];

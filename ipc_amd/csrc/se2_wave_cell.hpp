@@ -43,10 +43,37 @@ struct WaveScratch {          // per cell (one wave, or a pair of waves), LDS
 // my values, post my sequence number, wait for the partner's, read the partner's values", double
 // buffered on the sequence parity.  LDS operations of one wave complete in order, so the data is
 // visible before the flag.
+//
+// The payload is moved with RELAXED ATOMIC loads / stores (workgroup scope), not plain ones.  The instructions are the
+// same ds_read / ds_write, but (i) the protocol is then race-free for every lane by the memory model -- with plain
+// accesses only lane 0, which posts the flag, is ordered against the partner's next overwrite of the buffer; the other
+// lanes' reads are ordered by the wave's lock-step execution, which the model knows nothing about -- and (ii) the
+// compiler waits for a payload read where it is issued instead of leaving it in flight across the exec-mask juggling
+// and the branches that follow.  With plain accesses the kernels whose errors are recomputed (M > 8) give wrong,
+// run-to-run varying results when built with -mllvm -amdgpu-sched-strategy=max-ilp (round 4, DESIGN.md 7:
+// tools/maxilp_repro.py; the read of the partner's chi2 partial sum in the trial sweep is the one that matters);
+// with atomic accesses both scheduling strategies give bit-identical results.  -DIPC_MAILBOX_PLAIN restores the plain
+// accesses for that reproducer.
 struct PairBox {
     double data[4][2][8];     // [wave of the cell][parity][value]
     int flag[4];
 };
+__device__ __forceinline__ void mb_store(double* p, double v)
+{
+#ifdef IPC_MAILBOX_PLAIN
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ double mb_load(const double* p)
+{
+#ifdef IPC_MAILBOX_PLAIN
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 
 // what a wave does between two polls of its partner's mailbox flag
 #ifndef IPC_SPIN_SLEEP
@@ -161,7 +188,7 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
             double* my = box->data[wsub][seq & 1];
             if (lane == 0) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < n) my[k] = mine[k];
+                for (int k = 0; k < 8; ++k) if (k < n) mb_store(&my[k], mine[k]);
             }
             wave_sync();
             if (lane == 0) __hip_atomic_store(&box->flag[wsub], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -177,10 +204,13 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #ifdef IPC_PHASE_TIMING
             tmW += __builtin_amdgcn_s_memtime() - tw0;
 #endif
+#ifdef IPC_MB_DELAY_WAVE                               // (protocol stress: one wave of the cell dawdles behind every exchange)
+            if (wsub == IPC_MB_DELAY_WAVE) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#endif
             wave_sync();
         }
     };
-    auto peer = [&](int o, int k) -> double { return box->data[o][seq & 1][k]; };
+    auto peer = [&](int o, int k) -> double { return mb_load(&box->data[o][seq & 1][k]); };
     auto pair_barrier = [&]() {
         if constexpr (W > 1) { double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; post_wait(a, 0); }
     };
