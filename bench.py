@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-set-only", action="store_true", help="skip the set-only side measurement (kernel traces of the matrix steps alone)")
     ap.add_argument("--incremental-candidates", type=int, default=-1,
                     help="candidates of the faithful incremental mode to time (reference metric); -1: all of them for "
                          "the SE2 workloads at 1 GPU, none otherwise; 0: none")
@@ -359,7 +360,9 @@ def main():
     # (FETCH_SIZE / WRITE_SIZE in KB, separate passes; FETCH_SIZE doubled per the gfx950 note in
     # MI355X_MICROARCH.md).  Per step, like `achieved`.
     traffic = None
-    pmc_csv = os.path.join(ROOT, "profiles", "pmc_hbm_%s.csv" % args.workload)
+    pmc_csv = os.path.join(ROOT, "profiles", "r4_pmc_hbm_%s.csv" % args.workload)
+    if not os.path.exists(pmc_csv):
+        pmc_csv = os.path.join(ROOT, "profiles", "pmc_hbm_%s.csv" % args.workload)
     if os.path.exists(pmc_csv) and world == 1:
         import csv
         f = w = 0.0
@@ -389,9 +392,9 @@ def main():
                 "executed_fp64_flops_per_step": ex["flops"] if ex else None,
                 "executed_pass_is_of_this_build": ex["current"] if ex else None,
                 "mfma_mops_f64": ex["mfma_mops_f64"] if ex else None,
-                "traffic_note": "HBM bytes per step of the solver kernels, profiles/pmc_hbm_%s.csv (rocprofv3 --pmc "
-                                "FETCH_SIZE / WRITE_SIZE passes); mostly register-spill scratch, the chain itself is "
-                                "L2-resident" % args.workload,
+                "traffic_note": "HBM bytes per step of the solver kernels, %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                "passes, FETCH doubled per the gfx950 note); mostly register-spill scratch, the chain itself "
+                                "is L2-resident" % os.path.relpath(pmc_csv, ROOT),
                 "kernel": "%s (%d launches per step, one per chain-length bin and loop count)" % (
                     "se2_wave_kernel<M,NL,STAGED> + se2_group_kernel<W,M,NL,STAGED> + se2_cells_kernel<W,M,NL>" if g.dim == 2
                     else "se3_lds_kernel<W,M,NL> (+ se3_cells_kernel<W,M,NL> beyond 2560 poses)", launches),
@@ -444,7 +447,7 @@ def main():
             n_inc = N if g.dim == 2 and args.workload in ("C1", "C2", "tiny", "T700") else 0
         if n_inc > 0:
             out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5, args.workload)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_set_only:
         # reported separately, never the headline: the accepted SET without the cells the set-max never reads
         # (ipc_run_set_only: diagonal cells first, then the pairs among the candidates whose own cell passed)
         eng.run_set_only()

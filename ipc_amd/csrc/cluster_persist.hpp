@@ -377,7 +377,6 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
     const int i0 = k1 + bx * 64, j0 = k1 + by * 64;
     double (*Ai)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel);
     double (*Aj)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(panel + kLdsPanel);
-    const int tx = t & 15, ty = t >> 4;
     const unsigned long long ts0 = prof_now();
     // panel rows of the tile: 64 of Ai and 64 of Aj, two lanes per row on the sub-group's four waves
     constexpr int LPR = 2, NS = kCB / LPR;
@@ -413,43 +412,23 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
     if (has && j0 < n) {
         // the tile's old values: all sixteen loads in flight behind the product below (sc1: straight from memory;
         // one load - subtract - store per element would be sixteen round trips)
-        double old[4][4];
+        const TileOwn own{wv, lane};
+        double old[16];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + ty + 16 * b;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = i0 + tx + 16 * a;
-                const bool in = j < n && i <= n && i >= j;
-                old[a][b] = ld_shared(&A[in ? (size_t)j * ld + i : (size_t)0]);         // (always a valid address: no branch per element)
-            }
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + own.i_of(e), j = j0 + own.j_of(e);
+            const bool in = j < n && i <= n && i >= j;
+            old[e] = ld_shared(&A[in ? (size_t)j * ld + i : (size_t)0]);         // (always a valid address: no branch per element)
         }
-        double acc[4][4];
+        double acc[16];
+        tile_product(Ai, Aj, own, acc);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-        for (int p = 0; p < kCB; ++p) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { av[q] = Ai[p][tx + 16 * q]; bv[q] = Aj[p][ty + 16 * q]; }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + ty + 16 * b;
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + own.i_of(e), j = j0 + own.j_of(e);
             if (j >= n) continue;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = i0 + tx + 16 * a;
-                // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
-                if (skip_next_diag && i < min(k1 + kCB, n)) continue;       // (row n is the right-hand side, never part of it)
-                if (i <= n && i >= j) st_shared(&A[(size_t)j * ld + i], old[a][b] - acc[a][b]);
-            }
+            // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
+            if (skip_next_diag && i < min(k1 + kCB, n)) continue;       // (row n is the right-hand side, never part of it)
+            if (i <= n && i >= j) st_shared(&A[(size_t)j * ld + i], old[e] - acc[e]);
         }
     }
     __syncthreads();

@@ -25,6 +25,81 @@ __device__ __forceinline__ double rsqrt_newton(double x)
     return y;
 }
 
+// ---- the 64 x 64 x 32 tile product of the trailing update: C = Ai^T Aj (panels [32][65] in LDS) ------------------
+// The one dense contraction of the repo.  Two forms, same result bits (each C element is the FMA chain over p = 0 .. 31
+// starting from 0, which is also what the FP64 matrix core computes: v_mfma_f64_16x16x4_f64 adds its four products to
+// the accumulator one after the other, in k order, each step one fused multiply-add -- tests/test_gpu_persistent.py
+// holds the two forms against each other bit for bit):
+//   IPC_TILE_MFMA 0: 4 x 4 register block per thread of plain v_fma_f64 (rounds 2-3): 8 LDS reads per 16 FMAs;
+//   IPC_TILE_MFMA 1: v_mfma_f64_16x16x4_f64, wave w of the 256-thread group owns the 2 x 2 blocks of 16 x 16 with block
+//                    rows j in {2 (w >> 1), +1} and block columns i in {2 (w & 1), +1}: 4 LDS reads per 4 MFMAs
+//                    (= 64 FMAs per lane-equivalent), 8 k-steps.  The j index is the MFMA's row (A operand) so that the
+//                    result's fast lane index (lane & 15) runs along i, the contiguous direction of the column-major
+//                    matrix: lane l, register q of block (jj, ii) holds C[i = 16 bi + (l & 15)][j = 16 bj + (l >> 4) + 4 q].
+// MI355X's FP64 matrix rate equals its FP64 vector rate (78.6 TFLOP/s), so the gain is issue slots and LDS operand
+// traffic, not peak.
+#ifndef IPC_TILE_MFMA
+#define IPC_TILE_MFMA 1
+#endif
+typedef double tile_d4 __attribute__((ext_vector_type(4)));
+struct TileOwn {                                     // which elements of the tile a thread holds, in the order e = 0 .. 15
+    int wave, lane;
+    __device__ __forceinline__ int i_of(int e) const
+    {
+#if IPC_TILE_MFMA
+        return 16 * (2 * (wave & 1) + ((e >> 2) & 1)) + (lane & 15);
+#else
+        return (lane & 15) + 16 * (e & 3);           // tx + 16 a   (thread t of the group: tx = t & 15, ty = t >> 4)
+#endif
+    }
+    __device__ __forceinline__ int j_of(int e) const
+    {
+#if IPC_TILE_MFMA
+        return 16 * (2 * (wave >> 1) + (e >> 3)) + (lane >> 4) + 4 * (e & 3);
+#else
+        return (wave * 4 + (lane >> 4)) + 16 * (e >> 2);          // ty + 16 b
+#endif
+    }
+};
+// acc[e] = sum_p Ai[p][i_of(e)] * Aj[p][j_of(e)]; every lane of the four waves must be active (MFMA)
+__device__ __forceinline__ void tile_product(const double (*Ai)[64 + 1], const double (*Aj)[64 + 1], const TileOwn& own, double (&acc)[16])
+{
+#if IPC_TILE_MFMA
+    const int kq = own.lane >> 4, c = own.lane & 15;
+    const int i0 = 16 * 2 * (own.wave & 1) + c, j0 = 16 * 2 * (own.wave >> 1) + c;
+    tile_d4 d[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) d[jj][ii] = tile_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < kCB / 4; ++ks) {
+        const int p = 4 * ks + kq;
+        const double a0 = Aj[p][j0], a1 = Aj[p][j0 + 16], b0 = Ai[p][i0], b1 = Ai[p][i0 + 16];
+        d[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d[0][0], 0, 0, 0);
+        d[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, d[0][1], 0, 0, 0);
+        d[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d[1][0], 0, 0, 0);
+        d[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = d[e >> 3][(e >> 2) & 1][e & 3];
+#else
+    const int tx = own.lane & 15, ty = own.wave * 4 + (own.lane >> 4);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+#pragma unroll 8
+    for (int p = 0; p < kCB; ++p) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = Ai[p][tx + 16 * q]; bv[q] = Aj[p][ty + 16 * q]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a + 4 * b] = fma(av[a], bv[b], acc[a + 4 * b]);
+    }
+#endif
+}
+
 // One block column k0 .. k0+nb of the factorisation, one workgroup per 64 x 64 tile (bx >= by) of the trailing
 // matrix (rows k1 .. n, row n = right-hand side; columns k1 .. n-1):
 //   1. every workgroup loads the nb x nb diagonal block and its first wave factors it in registers (lane r holds
@@ -111,31 +186,13 @@ __global__ __launch_bounds__(256) void chol_step(double* A, double* Lf, int n, i
     }
     __syncthreads();
     if (j0 >= n) return;                                    // (a tile column of right-hand-side rows only)
-    const int tx = tid & 15, ty = tid >> 4;
-    double acc[4][4];
+    const TileOwn own{wave, lane};
+    double acc[16];
+    tile_product(Ai, Aj, own, acc);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-    for (int p = 0; p < kCB; ++p) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = Ai[p][tx + 16 * q]; bv[q] = Aj[p][ty + 16 * q]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int j = j0 + ty + 16 * b;
-        if (j >= n) continue;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = i0 + tx + 16 * a;
-            if (i <= n && i >= j) A[(size_t)j * ld + i] -= acc[a][b];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + own.i_of(e), j = j0 + own.j_of(e);
+        if (j < n && i <= n && i >= j) A[(size_t)j * ld + i] -= acc[e];
     }
 }
 

@@ -252,15 +252,25 @@ __global__ void k_se3_propagate(int V, const double* rec, int stride, double* po
 constexpr int kPlanSub = 32;
 // phase 0: every cell of this rank's rows; 1: the diagonal cells only; 2: the pair cells of candidates whose own cell
 // passed (diagonal bit set in `diag`, the shard of a one-rank run) -- the set-only mode of ipc_run_set_only
-__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* rowslot, BinCaps bc,
+// Rows are visited in the order of `rowperm` (rows sorted by the first vertex of their interval) and a bin's cell list is
+// the concatenation of kPlanSub sub-lists, sub-list s holding the rows of the s-th chunk of that order: the list ends up
+// sorted by chain position.  The cell kernels draw cells from the head of the list, so the cells in flight at any moment
+// are neighbours along the trajectory and their chain records are shared through L2 (C5, 21.6 MB of records against
+// 4 MB of L2 per XCD: round 3 fetched every record from beyond L2 in every pass, 35.8x the algorithmic bytes).  Blocks
+// that run side by side (consecutive u) land in different chunks, i.e. on different counters.
+__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* rowslot, const int* rowperm, BinCaps bc,
                        unsigned* counters, const unsigned* offsets, int2* cells, int fill, int phase = 0,
                        const unsigned long long* diag = nullptr, int words = 0)
 {
-    const int sub = (blockIdx.x + blockIdx.y) & (kPlanSub - 1);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;          // this thread's candidate, its interval read once
     const int loj = j < N ? lo[j] : 0, hij = j < N ? hi[j] : 0;
     const bool alivej = phase != 2 || (j < N && ((diag[(size_t)j * words + (j >> 6)] >> (j & 63)) & 1ull));
-    for (int i = blockIdx.y; i < N; i += gridDim.y) {
+    const int chunk = (N + kPlanSub - 1) / kPlanSub;
+    for (int u = blockIdx.y; u < chunk * kPlanSub; u += gridDim.y) {
+    const int sub = u & (kPlanSub - 1);
+    const int q = sub * chunk + (u / kPlanSub);                   // position in the row order
+    if (q >= N || (u / kPlanSub) >= chunk) continue;
+    const int i = rowperm[q];
     if (rowslot[i] / rpr != rank) continue;                       // rows of this rank (ipc_row_assignment)
     if (phase == 2 && !((diag[(size_t)i * words + (i >> 6)] >> (i & 63)) & 1ull)) continue;
     if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
@@ -554,6 +564,7 @@ struct ipc_engine {
     double* d_cand = nullptr; int cstride = 0;        // cstride = capacity in records (>= N): the list grows in place
     int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
     int* d_live = nullptr;                             // set-max: candidates with a set diagonal bit, in processing order
+    int* d_rowperm = nullptr;                          // rows in the order the planning pass visits them (by first vertex, then index)
     bool order_stale = false;                          // d_order is behind `order` (appends): re-sent by the next matrix-mode call
     std::vector<void*> retired;                        // candidate arrays a growth replaced while solves in flight may still read them
     hipEvent_t ev_cand = nullptr; bool cand_event = false;   // behind the last record written by ipc_append_candidate (own_stream)
@@ -851,6 +862,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
 static void free_candidates(ipc_engine* h)
 {
     hipFree(h->d_cand); hipFree(h->d_from); hipFree(h->d_to); hipFree(h->d_lo); hipFree(h->d_hi); hipFree(h->d_order); hipFree(h->d_live);
+    hipFree(h->d_rowperm); h->d_rowperm = nullptr;
     hipFree(h->d_slot); h->d_slot = nullptr; h->slot_world = 0;
     for (void* q : h->retired) hipFree(q);
     h->retired.clear();
@@ -869,6 +881,7 @@ static int alloc_candidates(ipc_engine* h, int cap)
     HIPCHK(hipMalloc(&h->d_hi, sizeof(int) * cap));
     HIPCHK(hipMalloc(&h->d_order, sizeof(int) * cap));
     HIPCHK(hipMalloc(&h->d_live, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_rowperm, sizeof(int) * cap));
     HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(double) * nf * (size_t)cap, h->own_stream));
     h->cstride = cap;
     return IPC_OK;
@@ -883,7 +896,7 @@ static int grow_candidates(ipc_engine* h, int need)
     int cap = std::max(64, h->cstride);
     while (cap < need) cap *= 2;
     double* o_cand = h->d_cand; const int o_stride = h->cstride;
-    int *o_from = h->d_from, *o_to = h->d_to, *o_lo = h->d_lo, *o_hi = h->d_hi, *o_order = h->d_order, *o_live = h->d_live;
+    int *o_from = h->d_from, *o_to = h->d_to, *o_lo = h->d_lo, *o_hi = h->d_hi, *o_order = h->d_order, *o_live = h->d_live, *o_perm = h->d_rowperm;
     if (int rc = alloc_candidates(h, cap)) return rc;
     if (h->N > 0) {
         HIPCHK(hipMemcpy2DAsync(h->d_cand, sizeof(double) * cap, o_cand, sizeof(double) * o_stride, sizeof(double) * h->N, nf,
@@ -893,7 +906,7 @@ static int grow_candidates(ipc_engine* h, int need)
         HIPCHK(hipMemcpyAsync(h->d_lo, o_lo, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
         HIPCHK(hipMemcpyAsync(h->d_hi, o_hi, sizeof(int) * h->N, hipMemcpyDeviceToDevice, h->own_stream));
     }
-    for (void* q : {(void*)o_cand, (void*)o_from, (void*)o_to, (void*)o_lo, (void*)o_hi, (void*)o_order, (void*)o_live})
+    for (void* q : {(void*)o_cand, (void*)o_from, (void*)o_to, (void*)o_lo, (void*)o_hi, (void*)o_order, (void*)o_live, (void*)o_perm})
         if (q) h->retired.push_back(q);
     h->order_stale = true;
     return IPC_OK;
@@ -961,6 +974,16 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     return IPC_OK;
 }
 
+// the order in which the planning pass visits the rows: by the first vertex of the candidate's interval, then by index
+static int upload_row_order(ipc_engine* h)
+{
+    std::vector<int> perm(h->N);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return h->h_lo[a] < h->h_lo[b]; });
+    HIPCHK(hipMemcpy(h->d_rowperm, perm.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+    return IPC_OK;
+}
+
 // Uploads the candidate list (file order); the consensus set and the current poses go back to the open-loop state.
 static int upload_candidates(ipc_engine* h, int n, const int* ids, const double* meas, const double* info)
 {
@@ -1005,6 +1028,7 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     HIPCHK(hipMemcpy(h->d_lo, h->h_lo.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_hi, h->h_hi.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_order, h->order.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    if (int rc = upload_row_order(h)) return rc;
     double *d_m = nullptr, *d_i = nullptr;
     HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * n));
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * n));
@@ -1032,6 +1056,7 @@ extern "C" int ipc_set_candidates(ipc_engine_t* h, int n, const int* ids, const 
 
 static void spec_insert_position(ipc_engine* h, int k);
 static void spec_move_to_head(ipc_engine* h, int k);
+
 
 // One more candidate at the end of the list (the harness hands IPC::agreementCheck an edge nobody announced,
 // reference src/simulation.cpp:34-47).  The consensus set, the poses and whatever the pipeline has in flight stay as they
@@ -1091,6 +1116,7 @@ static int matrix_mode_enter(ipc_engine* h, hipStream_t st)
     if (h->order_stale && h->N > 0) {
         HIPCHK(hipMemcpyAsync(h->d_order, h->order.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));     // (pageable source: the copy has left the host vector when this returns)
+        if (int rc = upload_row_order(h)) return rc;
         h->order_stale = false;
     }
     if (h->cand_event && st != h->own_stream) HIPCHK(hipStreamWaitEvent(st, h->ev_cand, 0));
@@ -1352,7 +1378,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     // pass 1: count
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
     const dim3 pgrid((N + 255) / 256, std::min(N, 2048)), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, (const int*)h->d_rowperm, bc, h->d_counters,
                        h->d_offsets, (int2*)nullptr, 0, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
@@ -1384,7 +1410,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     // pass 2: fill
     HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, bc, h->d_counters,
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, (const int*)h->d_rowperm, bc, h->d_counters,
                        h->d_offsets, h->d_cells, 1, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     // solve: longest chains first

@@ -1,9 +1,12 @@
 """Row-sharded consistency matrix across the GPUs of one node.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).  The chain and the
-candidate list are replicated; rank r solves the cells (i, j >= i) of the rows i with
-i % world == r (row-cyclic, which balances the triangular row lengths), producing bit rows
-[rows_per_rank, words].  ONE all-gather of those bit rows over xGMI reassembles the matrix on
+candidate list are replicated; rank r solves the cells (i, j >= i) of the rows the library's own
+assignment gives it (ipc_row_assignment: balanced by cost -- a row's cost is the number of poses its
+cells sweep -- costliest row first to the least loaded rank; IPC_ROW_BALANCE=cyclic keeps i % world),
+producing bit rows [rows_per_rank, words] (row i sits at slot[i] % rows_per_rank of its owner's shard).
+ipc_solve_rows blocks the host twice (plan counts; cells to solve again, see include/ipc_amd.h) and
+returns with everything else enqueued.  ONE all-gather of those bit rows over xGMI reassembles the matrix on
 every rank (N^2/8 bytes in total: 197 KB for C2, 78 MB for C5), after which every rank
 assembles the symmetric matrix and runs the (cheap, sequential-in-k) set-max redundantly, so no
 second collective is needed to publish the result.

@@ -252,3 +252,32 @@ def test_borderline_cells_are_solved_again_by_the_literal_loop(monkeypatch):
     monkeypatch.setenv("IPC_TERMINATE_EPS", "1e-13x")
     with pytest.raises(Exception, match="IPC_TERMINATE_EPS"):
         IPC(g, cfg, device=0)
+
+
+def test_c5_row_shards_of_eight_ranks_reassemble_to_the_single_gpu_matrix():
+    """BASELINE configs[4] in its own form -- SE3, N = 25 000, 8 ranks -- on one GPU: every rank's shard
+    (ipc_solve_rows with the library's cost-balanced row assignment) is computed in turn into the layout the RCCL
+    all-gather produces (rank-major, 8 x 3 125 rows x 391 words = 78 MB), then assembled and reduced: the same matrix
+    bits and the same consensus set as the one-rank run.  (The collective itself only runs in the driver's multi-GPU bench.)"""
+    from ipc_amd.dist import EngineBackend
+    g, cfg, eng, ref_bits, ref_acc = _run("C5")
+    world = 8
+    b = EngineBackend(eng)
+    rpr = (eng.N + world - 1) // world
+    gathered = b.empty_words(world * rpr * eng.words)
+    per_rank = []
+    with b.stream_ctx():
+        for r in range(world):
+            b.solve_rows(r, world, gathered[r * rpr * eng.words:(r + 1) * rpr * eng.words])
+            per_rank.append(len(eng.cell_info()))
+        bits = b.empty_words(eng.N * eng.words)
+        acc = b.empty_bytes(eng.N)
+        b.assemble(gathered, world, bits)
+        b.set_max(bits, acc)
+    b.stream.synchronize()
+    got = bits.cpu().numpy().view(np.uint64).reshape(eng.N, eng.words)
+    assert np.array_equal(got, ref_bits)
+    assert np.array_equal(acc.cpu().numpy(), ref_acc)
+    total = sum(per_rank)
+    assert max(per_rank) <= 1.25 * total / world, per_rank         # solved cells per rank: the cost balance holds on SE3 too
+    print("C5, 8 ranks: solved cells per rank", per_rank)
