@@ -220,10 +220,17 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
         if constexpr (W > 1) {
             double a[8] = {t0, t1, 0, 0, 0, 0, 0, 0};
             post_wait(a, 2);
-            s0 = wsub == 0 ? t0 : peer(0, 0);
-            s1 = wsub == 0 ? t1 : peer(0, 1);
+#if defined(IPC_MAILBOX_PLAIN) && defined(IPC_DBG_SUM_SIDE)    // (tools/maxilp_repro.py: which wave's read goes wrong)
+            auto rdx = [&](int o, int k) -> double {
+                return ((IPC_DBG_SUM_SIDE >> o) & 1) ? __hip_atomic_load(&box->data[o][seq & 1][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : peer(o, k);
+            };
+#else
+            auto rdx = [&](int o, int k) -> double { return peer(o, k); };
+#endif
+            s0 = wsub == 0 ? t0 : rdx(0, 0);
+            s1 = wsub == 0 ? t1 : rdx(0, 1);
 #pragma unroll
-            for (int o = 1; o < W; ++o) { s0 += o == wsub ? t0 : peer(o, 0); s1 += o == wsub ? t1 : peer(o, 1); }
+            for (int o = 1; o < W; ++o) { s0 += o == wsub ? t0 : rdx(o, 0); s1 += o == wsub ? t1 : rdx(o, 1); }
         } else { s0 = t0; s1 = t1; }
     };
     // exclusive prefix over the cell's lanes of a per-lane total
