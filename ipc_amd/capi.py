@@ -15,7 +15,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libipc_amd.so")
+LIB_PATH = os.environ.get("IPC_AMD_LIB") or os.path.join(_HERE, "libipc_amd.so")   # (IPC_AMD_LIB: A/B builds, tools/)
 
 # every symbol include/ipc_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    lib = os.path.join(ROOT, "ipc_amd", "libipc_amd.so")
+    lib = os.environ.get("IPC_LIB", os.path.join(ROOT, "ipc_amd", "libipc_amd.so"))
     pat = sys.argv[1] if len(sys.argv) > 1 else ""
     data = open(lib, "rb").read()
     pos = 0
