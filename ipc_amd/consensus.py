@@ -59,6 +59,17 @@ class IPC:
         self.N = ids.shape[0]
         self.ids = ids
 
+    def append_candidate(self, ids, meas, info):
+        """One more candidate at the end of the list (ipc_append_candidate: the harness hands agreementCheck an edge
+        nobody announced, reference src/simulation.cpp:34-47); returns its index.  State and solves in flight stay."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(2)
+        meas, info = _d(meas), _d(info)
+        k = C.c_int(-1)
+        capi.check(self.lib.ipc_append_candidate(self.h, _p(ids), _p(meas), _p(info), C.byref(k)))
+        self.N = k.value + 1
+        self.ids = np.vstack([self.ids, ids.reshape(1, 2)]) if self.N > 1 else ids.reshape(1, 2)
+        return k.value
+
     def candidate_order(self):
         order = np.zeros(self.N, dtype=np.int32)
         capi.check(self.lib.ipc_candidate_order(self.h, _p(order)))

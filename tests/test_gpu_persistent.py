@@ -171,6 +171,82 @@ def test_speculative_window_is_exact(window):
         assert np.float64(ia.max_chi2).tobytes() == np.float64(ib.max_chi2).tobytes()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_pipeline_under_random_orders_appends_rechecks_and_set_edits_is_exact(seed):
+    """Round 4: the pipeline's order is only a prediction of the caller's.  A random mix of in-order checks, checks far off
+    the order, candidates appended mid-run (ipc_append_candidate: solves in flight stay), re-checks of candidates already
+    handed out and edits of the set -- the same sequence on a one-at-a-time engine (window 1) and on the pipeline: every
+    check returns the same bits (decision, cluster, iterations, trials, chi2), and the final poses / set are equal."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    g = synth._se2_graph(400, 24, seed=81, laps=3.0, name="inc")
+    g = synth.inject_outliers(g, 40, seed=2)
+    cfg = Config()
+    rng = np.random.default_rng(seed)
+    n0 = 36 + int(rng.integers(0, 12))                       # announced at construction; the rest arrive one by one
+    perm = rng.permutation(g.N)
+    first, later = perm[:n0], list(perm[n0:])
+    engines = [_engine(g.subset(first), cfg, "persist", IPC_SPEC_WINDOW=w) for w in (1, 8)]
+    for e in engines:
+        e.reset()
+    known = [int(k) for k in first]                          # engine index -> candidate of g
+    todo = list(np.argsort(g.loop_ids[first].max(axis=1), kind="stable"))      # engine indices in cmpTime order
+    done = []
+    n_ops = {"next": 0, "far": 0, "append": 0, "recheck": 0, "edit": 0}
+    while todo or later:
+        u = rng.random()
+        if later and (u < 0.15 or not todo):
+            c = later.pop()
+            ks = [e.append_candidate(g.loop_ids[c], g.loop_meas[c], g.loop_info[c]) for e in engines]
+            assert ks[0] == ks[1] == len(known)
+            known.append(int(c))
+            # (where the harness's order would put it: behind everything that ends at or before its later vertex)
+            hi = g.loop_ids[c].max()
+            pos = len(todo)
+            while pos > 0 and g.loop_ids[known[todo[pos - 1]]].max() > hi:
+                pos -= 1
+            todo.insert(pos, ks[0])
+            n_ops["append"] += 1
+            if rng.random() < 0.5:
+                continue
+            k = ks[0]; todo.remove(k); op = "far"            # ... and checked at once, as the adapter does
+        elif done and u < 0.22:
+            k = done[int(rng.integers(0, len(done)))]; op = "recheck"
+        elif done and u < 0.26 and len(engines[0].getMaxConsensusSet()):
+            cs = [list(e.getMaxConsensusSet()) for e in engines]
+            assert cs[0] == cs[1]
+            victim = cs[0][int(rng.integers(0, len(cs[0])))]
+            r = [e.removeEdgeFromCnS(victim) for e in engines]
+            assert r[0] == r[1]
+            if rng.random() < 0.5:
+                for e in engines:
+                    e.addEdgeToCnS(victim)
+            n_ops["edit"] += 1
+            continue
+        elif u < 0.75 or len(todo) < 3:
+            k = todo.pop(0); op = "next"
+        else:
+            k = todo.pop(int(rng.integers(1, len(todo)))); op = "far"
+        n_ops[op] += 1
+        res = [e.agreementCheck(int(k), with_info=True) for e in engines]
+        (oa, ia), (ob, ib) = res
+        assert oa == ob, (op, k)
+        assert (ia.lo, ia.hi, ia.n_cluster_loops, ia.iterations, ia.tries, ia.flags) == (ib.lo, ib.hi, ib.n_cluster_loops, ib.iterations, ib.tries, ib.flags), (op, k)
+        assert np.float64(ia.max_chi2).tobytes() == np.float64(ib.max_chi2).tobytes(), (op, k)
+        if op != "recheck":
+            done.append(k)
+    assert n_ops["far"] >= 5 and n_ops["append"] >= 5
+    assert np.array_equal(engines[0].current_poses().view(np.uint64), engines[1].current_poses().view(np.uint64))
+    assert np.array_equal(engines[0].getMaxConsensusSet(), engines[1].getMaxConsensusSet())
+    # and the appended list is the list: matrix mode on it equals matrix mode on a fresh engine with the same candidates
+    fresh = _engine(g.subset(np.array(known)), cfg, "persist")
+    b0, a0 = engines[1].run()
+    b1, a1 = fresh.run()
+    assert np.array_equal(b0, b1) and np.array_equal(a0, a1)
+    for e in engines + [fresh]:
+        e.close()
+
+
 def test_pipeline_is_bitwise_on_c1_clusters_of_253_loops():
     """BASELINE configs[0] through the pipeline (71 % of the candidates accepted: tentative states made and dropped all the
     time, pose buffers recycled while copies are still queued) -- every check returns the bits of the one-at-a-time run,
