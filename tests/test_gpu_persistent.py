@@ -380,6 +380,14 @@ def test_se3_faithful_run_against_the_oracle_fixture():
     assert big >= 40
 
 
+def test_c4m_faithful_run_against_the_oracle_fixture():
+    """Round 4: sphere2500-like SE3 graph (V = 2500), every 10th true loop + 200 outliers, all 445 candidates: 244
+    accepted, clusters up to 244 loops = 1 464 unknowns -- the SE3 capacitance system across 23 tile rows, helpers and
+    the leader's look-ahead at full stretch -- against the CPU oracle's run (180 s on one thread, committed fixture)."""
+    worst, big = _replay("C4m", "c4m", 1e-6)
+    assert big >= 240
+
+
 def test_c2_faithful_run_against_the_oracle_fixture():
     """bench.py workload C2 (the north-star configuration), all 1256 candidates."""
     worst, big = _replay("C2", "c2", 1e-6)
