@@ -1886,22 +1886,20 @@ __global__ void k_nap(unsigned long long ticks)             // (100 MHz wall clo
 
 // How many of `n` streams really run side by side: streams that share a hardware queue run their kernels one after the
 // other, and how many queues the runtime has was decided at ITS initialisation (GPU_MAX_HW_QUEUES), which this library
-// may or may not have been in time for.  One 200 us nap per stream, all at once: the wall time says how many ran abreast.
+// may or may not have been in time for.  One 1 ms nap per stream, all at once: the wall time says how many ran abreast
+// (tools/microbench/stream_concurrency.cpp: 3.9 with 4 queues, 7.5 with 8, 13.8 of 16 with 16, 19.4 of 24 with 32 -- and a
+// collapse to < 1 beyond ~24 streams, whatever the variable says).
 static int probe_stream_concurrency(hipStream_t* st, int n)
 {
     if (n <= 1) return n;
-    const unsigned long long nap = 20000;                  // 200 us
+    const unsigned long long nap = 100000;                 // 1 ms
     for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k_nap, dim3(1), dim3(64), 0, st[q], 100ull);    // (code object loaded, queues created)
     for (int q = 0; q < n; ++q) if (hipStreamSynchronize(st[q]) != hipSuccess) return 1;
-    double best = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k_nap, dim3(1), dim3(64), 0, st[q], nap);
-        for (int q = 0; q < n; ++q) if (hipStreamSynchronize(st[q]) != hipSuccess) return 1;
-        best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    }
-    const double rounds = std::max(1.0, best / 200e-6 - 0.35);             // (launch + sync overhead of the probe itself)
-    return std::max(1, std::min(n, (int)std::lround(n / rounds)));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int q = 0; q < n; ++q) hipLaunchKernelGGL(k_nap, dim3(1), dim3(64), 0, st[q], nap);
+    for (int q = 0; q < n; ++q) if (hipStreamSynchronize(st[q]) != hipSuccess) return 1;
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return std::max(1, std::min(n, (int)std::lround(n * 1e-3 / std::max(wall - 0.1e-3, 1e-3))));
 }
 
 static int spec_ensure(ipc_engine* h)

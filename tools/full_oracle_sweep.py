@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Compare EVERY solved cell of a bench workload (GPU, through the C ABI) with the CPU oracle on all host cores:
-decisions (max chi2 <= threshold) and max chi2.  Too long for the test suite (C2: 531 545 cells, ~13 min on the
-256-core GPU box), so it is run by hand and its summary is committed under profiles/.
+decisions (max chi2 <= threshold) and max chi2.  Too long for the test suite (C2: 531 545 cells, ~8 min on the
+16 CPUs a GPU box grants), so it is run by hand and its summary is committed under profiles/.
 
 usage (GPU box): python tools/full_oracle_sweep.py C2 out.json [--max-seconds 1500] [--seed 0]
 Cells are visited in random order in chunks, so a run cut short by --max-seconds is an unbiased sample."""
@@ -27,7 +27,8 @@ def main():
     cells = eng.cell_info()
     O.build()
     poses = O.propagate(g.dim, g.odom_meas)
-    cores = os.cpu_count() or 1
+    import bench
+    cores = bench.effective_cores()                    # (the GPU boxes show 256 logical CPUs and grant 16)
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     rng = np.random.default_rng(seed)
     order = rng.permutation(len(cells))
