@@ -31,7 +31,8 @@ def test_mailbox_payload_is_moved_with_atomic_accesses():
         body = re.sub(r"//[^\n]*", "", txt)
         for m in re.finditer(r"box->data\[[^;]*;", body):
             stmt = m.group(0)
-            assert "mb_load(" in body[max(0, m.start() - 40):m.end()] or "mb_store(" in body[max(0, m.start() - 40):m.end()] \
+            ctx = body[max(0, m.start() - 40):m.end()]
+            assert "mb_load(" in ctx or "mb_store(" in ctx or "__hip_atomic_load(" in ctx \
                 or re.match(r"box->data\[wsub\]\[seq & 1\];", stmt), stmt
     assert "__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)" in cell
     assert "__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)" in cell
