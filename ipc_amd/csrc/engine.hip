@@ -630,6 +630,7 @@ struct ipc_engine {
         int state = -1;                                // index of the pose state it started from (spec_states)
         int launch_id = 0;
         int busy_wgs = 0;                              // workgroups of the last launch until its `done` completes (also after an abort)
+        std::chrono::steady_clock::time_point t_launch;   // (IPC_SPEC_STATS: launch-to-collect time per dog-leg iteration)
         int lo = 0, hi = 0, nclu = 0;
         double th = 0.0;
     };
@@ -661,11 +662,12 @@ struct ipc_engine {
     std::vector<int> porder, ppos;
     std::vector<char> handed;                          // by candidate: its verdict has been handed to the caller since the last reset
     int spec_head = -1;                                // next position to hand out; -1: pipeline empty
-    int spec_window = 4, spec_ahead = 64;              // solves in flight / positions ahead of the head (IPC_SPEC_AHEAD)
+    int spec_window = 4, spec_ahead = 256;             // solves in flight / positions ahead of the head (IPC_SPEC_AHEAD)
     bool window_forced = false;                        // IPC_SPEC_WINDOW given: taken as is, no probe
     int stream_concurrency = 0;                        // streams of the window measured to run side by side (diagnostic)
     double accept_rate = 0.5;                          // running mean over the recent verdicts: how far ahead it pays to assume "reject"
     int helper_limit = 39;
+    double st_acc_s = 0, st_rej_s = 0; long st_acc_it = 0, st_rej_it = 0, st_acc_n = 0, st_rej_n = 0;   // IPC_SPEC_STATS
     unsigned long long commit_count = 0;
     hipEvent_t ev_commit = nullptr;
     int* h_abort = nullptr;                            // host-mapped: one word per slot, the launch id to give up
@@ -954,9 +956,13 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (h->d_prof || getenv("IPC_SPEC_STATS"))
         fprintf(stderr, "{\"speculation\": {\"window\": %d, \"streams_abreast\": %d, \"persist_timeouts\": %ld, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
                         "\"tentative_states\": %ld, \"promoted\": %ld, \"host_s_in_checks\": %.3f, \"host_s_launching\": %.3f, "
-                        "\"host_s_tentative\": %.3f}}\n",
+                        "\"host_s_tentative\": %.3f, "
+                        "\"accept_solves\": %ld, \"accept_us_per_iteration\": %.1f, \"accept_ms_per_solve\": %.2f, "
+                        "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f}}\n",
                 h->spec_window, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
-                h->spec_t_total, h->spec_t_launch, h->spec_t_tent);
+                h->spec_t_total, h->spec_t_launch, h->spec_t_tent,
+                h->st_acc_n, 1e6 * h->st_acc_s / std::max(1L, h->st_acc_it), 1e3 * h->st_acc_s / std::max(1L, h->st_acc_n),
+                h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n));
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
     if (h->h_abort) hipHostFree(h->h_abort);
     delete h->persist2;
@@ -2050,6 +2056,7 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers)
                              h->h_from.data(), h->h_to.data(), c.iters));
     }
     HIPCHK(hipEventRecord(sl.done, sl.st));
+    sl.t_launch = std::chrono::steady_clock::now();
     // (a kernel this slot was told to give up may still be running in front of the new one, never beside it)
     sl.busy_wgs = std::max(sl.busy_wgs, h->dim == 3 ? sl.s3->workgroups() : sl.s2->workgroups());
     return IPC_OK;
@@ -2193,6 +2200,11 @@ static int spec_pump(ipc_engine* h)
         R.valid = true; R.state = sl.state; R.lo = sl.lo; R.hi = sl.hi; R.nclu = sl.nclu; R.o = o;
         R.retry_host = lost || ((o.flags & 2) && h->lm_retry);                // (decided when its turn comes, by the host-driven solver)
         R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
+        {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - sl.t_launch).count();
+            if (R.agree) { h->st_acc_s += dt; h->st_acc_it += o.iterations; ++h->st_acc_n; }
+            else { h->st_rej_s += dt; h->st_rej_it += o.iterations; ++h->st_rej_n; }
+        }
         fin_pos[nfin] = p; fin_slot[nfin] = q; ++nfin;
     }
     for (int a = 0; a < nfin; ++a)                                            // by position (a handful at most)
