@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         if (tid == 0) __hip_atomic_store(&P.ctl->cmd, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         grid_barrier(gb);
     }
-    // per-edge chi2 of the committed state and their maximum (a NaN makes the maximum NaN: `chi2 > th` is then false)
+    // per-edge chi2 of the committed state and their maximum (over the edges that have a number; NaN only if none of them is positive)
     { const Dev Dv = view(vsel); lead_for(nidx, [&](int i) { T::chi_edges(Dv, i); }); }
     {
         double mx = 0.0;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
         if (tid == 0) {
             double m = 0.0, f = 0.0;
             for (int w = 0; w < kPT / 64; ++w) { m = fmax(m, red[w]); f += red[16 + w]; }
-            o.max_chi2 = f != 0.0 ? __builtin_nan("") : m;
+            o.max_chi2 = (f != 0.0 && !(m > 0.0)) ? __builtin_nan("") : m;
             o.chi2_total = currentChi;
             o.x_sel = n_commit & 1;
             o.error = !alive ? 1 : (aborted ? 2 : 0);

@@ -857,7 +857,7 @@ inline hipError_t ClusterSolver3::max_edge_chi2(double& mx_out)
     double mx = 0.0;
     bool nan = false;
     for (double c : chi) { if (c != c) nan = true; else mx = std::max(mx, c); }
-    mx_out = nan ? std::nan("") : mx;
+    mx_out = (nan && !(mx > 0.0)) ? std::nan("") : mx;      // (max over the edges that have a number: se2_cell.hpp)
     return hipSuccess;
 }
 

@@ -1178,7 +1178,9 @@ __device__ void se3_solve_cell(const Se3View& P, int lo_abs, int L, const int (&
         if (c != c) nan = true;
         else mx = fmax(mx, c);
     }
-    if (nan) mx = __longlong_as_double(0x7ff8000000000000ll);
+    // consensus_utils.cpp:17-19 rejects as soon as ONE edge has chi2 > th; a NaN chi2 is not "> th".  So the maximum is
+    // taken over the edges that have a number, and NaN is reported only when none of them is positive (agrees either way).
+    if (nan && !(mx > 0.0)) mx = __longlong_as_double(0x7ff8000000000000ll);
     res.max_chi2 = mx;
     res.chi2_total = currentChi;
     res.iterations = it_done;

@@ -688,12 +688,18 @@ double oracle_solve_cell(int dim, const double *odom_meas, const double *odom_in
     iter = s.ne > 100 ? iter * 5 : iter;                          /* consensus_utils.cpp:12-13 */
     sub_optimize(&s, iter, &st);                                  /* consensus_utils.cpp:14 */
     st.chi2_final = sub_compute_errors(&s);                       /* consensus_utils.cpp:15 */
+    /* consensus_utils.cpp:17-19 returns false as soon as ONE edge has chi2 > th, and a NaN chi2 is not "> th": the  */
+    /* decision is (max over the edges that have a number) > th.  NaN is reported only when no edge has a positive   */
+    /* number (the check agrees either way).  Rounds 1-3 let one NaN edge mask the others.                           */
     double mx = 0;
-    for (int e = 0; e < s.ne; ++e) {                              /* consensus_utils.cpp:17-19 */
+    int any_nan = 0;
+    for (int e = 0; e < s.ne; ++e) {
         double c = edge_chi2(&s, e);
         if (chi2_out) chi2_out[e] = c;
-        if (c > mx || c != c) mx = c;
+        if (c != c) any_nan = 1;
+        else if (c > mx) mx = c;
     }
+    if (any_nan && !(mx > 0)) mx = NAN;
     if (poses_out) memcpy(poses_out, s.X, sizeof(double) * (size_t)(s.L + 1) * s.ps);
     if (stats) *stats = st;
     sub_free(&s);

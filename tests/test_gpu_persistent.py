@@ -484,3 +484,37 @@ def test_levenberg_retry_on_degenerate_information_incremental(oracle, mode):
         damped += bool(info.flags & 4)
     assert damped > 0
     assert np.array_equal(eng.getMaxConsensusSet(), inc.consensus())
+
+
+def test_a_nan_edge_does_not_mask_an_edge_above_the_threshold(oracle):
+    """src/consensus_utils.cpp:17-19 returns false as soon as ONE edge has chi2 > th; an edge whose chi2 is NaN is simply
+    not above it.  One odometry edge with NaN information: every solve across it fails at once (NaN pivot, also under the
+    Levenberg retry) and ends at the open-loop poses, where that edge's chi2 is NaN and the loop edges' are numbers.
+    Rounds 1-3 reported NaN (= agrees) for such cells, oracle and kernels alike; now an outlier across the NaN edge is
+    rejected, a candidate whose edges all stay below the threshold still agrees -- same bits from the oracle and the GPU."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import IPC, Config, unpack_bits
+    O = oracle
+    g = synth.inject_outliers(synth.small_se2(), 6, seed=3)
+    oi = g.odom_info.copy()
+    oi[40] = np.nan
+    g.odom_info = oi
+    cfg = Config()
+    eng = IPC(g, cfg, device=0)
+    bits, acc = eng.run()
+    ok, mx = O.consistency_matrix(2, g.odom_meas, g.odom_info, cfg.s_factor, g.loop_ids, g.loop_meas, g.loop_info,
+                                  cfg.fast_reject_th, cfg.fast_reject_iter_base, cfg.slow_reject_th, cfg.slow_reject_iter_base)
+    C = unpack_bits(bits, eng.N)
+    assert np.array_equal(C, ok)
+    assert np.array_equal(acc, O.set_max(ok, O.candidate_order(g.loop_ids)))
+    cells = eng.cell_info()
+    across = (cells["lo"] <= 40) & (cells["hi"] > 40)                 # cells whose chain holds the NaN edge
+    assert across.sum() > 10
+    th = np.where(cells["i"] == cells["j"], cfg.fast_reject_th, cfg.slow_reject_th)
+    rejected = across & (cells["max_chi2"] > th)
+    assert rejected.sum() > 0, "no cell across the NaN edge was rejected on a numbered edge"
+    assert not np.isnan(cells["max_chi2"][rejected]).any()
+    ref = np.array([mx[c["i"], c["j"]] for c in cells])
+    both = ~np.isnan(ref) & ~np.isnan(cells["max_chi2"])
+    assert np.array_equal(np.isnan(ref), np.isnan(cells["max_chi2"]))
+    assert (np.abs(cells["max_chi2"][both] - ref[both]) <= 1e-5 * np.maximum(np.abs(ref[both]), 1e-9)).all()
