@@ -1706,56 +1706,61 @@ __global__ void k_se3_propagate_tail(int V, int start, const double* rec, int st
 }
 
 // The accept branch of IPC::agreementCheck (src/consensus.cpp:69-71) in one launch: dst = parent outside the window, the
-// optimised poses inside lo..hi, then propagateCurrentGuess (consensus_utils.cpp:61-71) down the tail -- the serial
-// compose of k_se*_propagate_tail, same operations in the same order, but with the measurement records staged through
-// LDS by the whole workgroup a chunk at a time (the one lane that composes no longer waits for memory at every pose).
-// NF = 5 (SE2: x, y, theta, cos, sin) or 12 (SE3: R row-major, t); X = the solver's arrays [NF][ldx], window index 0 = lo.
-constexpr int kAcceptChunk = 256;
+// optimised poses inside lo..hi, then propagateCurrentGuess (consensus_utils.cpp:61-71) down the tail.  The reference
+// composes the tail pose by pose, v[i] = v[i-1] (+) z[i-1]; since every pose behind hi is then pure odometry on top of
+// v[hi], v[i] = v[hi] (+) (z[hi] ... z[i-1]) = (v[hi] (+) P[hi]^-1) (+) P[i] with P the open-loop poses the engine computed
+// once (propagateGuess from the origin, the same chain of compositions): ONE rigid transform applied to the open-loop
+// pose, every tail pose in parallel instead of a serial chain of up to V composes on one lane (round 3: 128 us per accept
+// on C2's trajectory, on the critical path of everything behind the accept).  The two forms differ by rounding only.
+// NF = 5 (SE2: x, y, theta, cos, sin; open = [5][V]) or 12 (SE3: R row-major, t; open = [12][V]); X = the solver's
+// arrays [NF][ldx], window index 0 = lo.
 template <int NF>
 __global__ __launch_bounds__(256) void k_apply_accept(int V, int lo, int hi, const double* parent, const double* X, int ldx,
-                                                      const double* rec, int stride, double* dst)
+                                                      const double* open, double* dst)
 {
-    constexpr int NR = NF == 5 ? 3 : 12;                       // record fields the compose reads
-    __shared__ double sh[kAcceptChunk * NR];
     const int tid = threadIdx.x;
     for (int q = tid; q < NF * V; q += 256) {
         const int f = q / V, i = q - f * V;
         if (i >= lo && i <= hi) dst[q] = X[(size_t)f * ldx + (i - lo)];
         else if (i < lo && dst != parent) dst[q] = parent[q];
     }
-    double st[NF];
-    if (tid == 0)
-        for (int f = 0; f < NF; ++f) st[f] = X[(size_t)f * ldx + (hi - lo)];
-    for (int base = hi + 1; base < V; base += kAcceptChunk) {
-        const int cnt = min(kAcceptChunk, V - base);
-        __syncthreads();
-        for (int q = tid; q < cnt * NR; q += 256) {
-            const int r = q / cnt, i = q - r * cnt;
-            int field;
-            if (NF == 5) field = r == 0 ? (int)F_TZX : (r == 1 ? (int)F_TZY : (int)F_THZ);
-            else field = r < 9 ? (int)G_RZ + r : (int)G_TZ + (r - 9);
-            sh[r * kAcceptChunk + i] = rec[(size_t)field * stride + base + i - 1];
+    if (hi + 1 >= V) return;
+    const size_t Vs = (size_t)V;
+    if (NF == 5) {
+        // D = T (+) P^-1: theta_D = theta_T - theta_P, t_D = t_T - R_D t_P
+        const double thT = X[2 * (size_t)ldx + (hi - lo)], thP = open[2 * Vs + hi];
+        const double thD = normalize_theta(thT - thP);
+        double sD, cD;
+        sincos_pi(thD, sD, cD);
+        const double xP = open[hi], yP = open[Vs + hi];
+        const double xD = X[hi - lo] - (cD * xP - sD * yP), yD = X[(size_t)ldx + (hi - lo)] - (sD * xP + cD * yP);
+        for (int i = hi + 1 + tid; i < V; i += 256) {
+            const double x = open[i], y = open[Vs + i];
+            const double th = normalize_theta(thD + open[2 * Vs + i]);
+            double sn, cs;
+            sincos_pi(th, sn, cs);
+            dst[i] = xD + (cD * x - sD * y);
+            dst[Vs + i] = yD + (sD * x + cD * y);
+            dst[2 * Vs + i] = th;
+            dst[3 * Vs + i] = cs;
+            dst[4 * Vs + i] = sn;
         }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 0; i < cnt; ++i) {
-                if (NF == 5) {
-                    const double tx = sh[i], ty = sh[kAcceptChunk + i];
-                    st[0] += st[3] * tx - st[4] * ty;
-                    st[1] += st[4] * tx + st[3] * ty;
-                    st[2] = normalize_theta(st[2] + sh[2 * kAcceptChunk + i]);
-                    sincos_pi(st[2], st[4], st[3]);
-                } else {
-                    double Rz[9], tz[3], Rn[9], d[3];
-                    for (int q = 0; q < 9; ++q) Rz[q] = sh[q * kAcceptChunk + i];
-                    for (int q = 0; q < 3; ++q) tz[q] = sh[(9 + q) * kAcceptChunk + i];
-                    m3_mul(st, Rz, Rn);
-                    m3_vec(st, tz, d);
-                    for (int q = 0; q < 3; ++q) st[9 + q] += d[q];
-                    for (int q = 0; q < 9; ++q) st[q] = Rn[q];
-                }
-                for (int f = 0; f < NF; ++f) dst[(size_t)f * V + base + i] = st[f];
-            }
+    } else {
+        double RT[9], tT[3], RP[9], tP[3], RD[9], tD[3], d[3];
+        for (int q = 0; q < 9; ++q) { RT[q] = X[(size_t)q * ldx + (hi - lo)]; RP[q] = open[(size_t)q * Vs + hi]; }
+        for (int q = 0; q < 3; ++q) { tT[q] = X[(size_t)(9 + q) * ldx + (hi - lo)]; tP[q] = open[(size_t)(9 + q) * Vs + hi]; }
+        for (int r = 0; r < 3; ++r)                             // R_D = R_T R_P^T
+            for (int c = 0; c < 3; ++c) RD[3 * r + c] = RT[3 * r] * RP[3 * c] + RT[3 * r + 1] * RP[3 * c + 1] + RT[3 * r + 2] * RP[3 * c + 2];
+        m3_vec(RD, tP, d);
+        for (int q = 0; q < 3; ++q) tD[q] = tT[q] - d[q];
+        for (int i = hi + 1 + tid; i < V; i += 256) {
+            double Ri[9], ti[3], Rn[9];
+            for (int q = 0; q < 9; ++q) Ri[q] = open[(size_t)q * Vs + i];
+            for (int q = 0; q < 3; ++q) ti[q] = open[(size_t)(9 + q) * Vs + i];
+            m3_mul(RD, Ri, Rn);
+            m3_vec(RD, ti, d);
+            for (int q = 0; q < 9; ++q) dst[(size_t)q * Vs + i] = Rn[q];
+            for (int q = 0; q < 3; ++q) dst[(size_t)(9 + q) * Vs + i] = tD[q] + d[q];
         }
     }
 }
@@ -1866,12 +1871,12 @@ static int apply_accept(ipc_engine* h, hipStream_t st, double* dst, const double
                         const double* X3, int ld3)
 {
     if (h->dim == 3)
-        hipLaunchKernelGGL(k_apply_accept<12>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X3, ld3, h->d_chain, h->estride, dst);
+        hipLaunchKernelGGL(k_apply_accept<12>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X3, ld3, (const double*)h->d_open, dst);
     else if (X2->th - X2->y != X2->y - X2->x || X2->c - X2->th != X2->y - X2->x || X2->s - X2->c != X2->y - X2->x)
         return fail(IPC_ERR_STATE, "apply_accept: the solver's pose arrays are not rows of one block");
     else                                            // (x, y, th, c, s: rows of one block, ClusterSolver2 / PersistSe2::carve)
-        hipLaunchKernelGGL(k_apply_accept<5>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X2->x, (int)(X2->y - X2->x), h->d_chain,
-                           h->estride, dst);
+        hipLaunchKernelGGL(k_apply_accept<5>, dim3(1), dim3(256), 0, st, h->V, lo, hi, parent, X2->x, (int)(X2->y - X2->x),
+                           (const double*)h->d_open, dst);
     HIPCHK(hipGetLastError());
     return IPC_OK;
 }
