@@ -262,7 +262,7 @@ def executed_flops(workload, dim):
     """Executed FP64 flops of the cell-solver kernels of ONE solve of this workload, from the committed rocprofv3 PMC
     pass profiles/r<round>_<workload>_pmc_sq.csv (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 are wave-level instruction
     counts: x 64 lanes, FMA = 2 flops).  `current` says whether the pass was taken on the kernel sources of this build
-    (sidecar .meta.json written by tools/profile_pmc.sh; passes without one predate the check).  None: no such file."""
+    (sidecar .meta.json written by tools/r4_profile.sh sq; passes without one predate the check).  None: no such file."""
     import csv
     for rnd in ("r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.csv" % (rnd, workload.lower()))
