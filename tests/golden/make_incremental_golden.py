@@ -10,12 +10,13 @@ The CPU oracle (oracle/ipc_oracle.c, test infrastructure) runs the whole candida
   se3 small sphere SE3 (bench.py workload C4s: V=500, 60 true loops + 60 outliers): clusters of >= 40 loops
   c4m sphere2500-like SE3 (bench.py workload C4m: V=2500, every 10th true loop + 200 outliers): clusters up to 244
       loops = 1 464 unknowns (round 4; 181 s)
+  c3  bench.py workload C3 (MIT-like SE2, V=808, 20 true loops + 5000 outliers): 5 020 candidates, 9 accepted (round 4; 101 s)
 
 and records per candidate (in processing order): decision, cluster span lo/hi, cluster size,
 max edge chi2.  The workloads themselves are regenerated from their seeds by ipc_amd.synth (the
 fixtures hold only the expectations, a few KB each).  Run time here: c1 ~2 min, c2 ~10 min, se3 ~1 min.
 
-usage: python tests/golden/make_incremental_golden.py [c1] [c2] [se3] [c4m]
+usage: python tests/golden/make_incremental_golden.py [c1] [c2] [se3] [c4m] [c3]
 """
 import os
 import sys
@@ -28,7 +29,7 @@ import numpy as np
 
 from oracle import oracle as O
 
-WORKLOAD = {"c1": "C1", "c2": "C2", "se3": "C4s", "c4m": "C4m"}
+WORKLOAD = {"c1": "C1", "c2": "C2", "se3": "C4s", "c4m": "C4m", "c3": "C3"}
 
 
 def run(tag):

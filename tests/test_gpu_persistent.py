@@ -388,6 +388,13 @@ def test_c4m_faithful_run_against_the_oracle_fixture():
     assert big >= 240
 
 
+def test_c3_faithful_run_against_the_oracle_fixture():
+    """Round 4: BASELINE configs[2] (MIT-like SE2, V = 808, 20 true loops + 5000 outliers) in the faithful mode, all 5 020
+    candidates (9 accepted, 36 vertex pairs with two candidates each) against the CPU oracle's run (101 s on one thread)."""
+    worst, big = _replay("C3", "c3", 1e-6)
+    assert big >= 8
+
+
 def test_c2_faithful_run_against_the_oracle_fixture():
     """bench.py workload C2 (the north-star configuration), all 1256 candidates."""
     worst, big = _replay("C2", "c2", 1e-6)
