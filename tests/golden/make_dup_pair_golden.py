@@ -44,6 +44,48 @@ def run(g):
     return inc, order, dec
 
 
+def rel_pose3(pa, pb):
+    """poses as the oracle keeps them ([R row-major (9), t (3)]) -> x y z qx qy qz qw of Xa^-1 Xb"""
+    from scipy.spatial.transform import Rotation
+    Ra, ta, Rb, tb = pa[:9].reshape(3, 3), pa[9:], pb[:9].reshape(3, 3), pb[9:]
+    R, t = Ra.T @ Rb, Ra.T @ (tb - ta)
+    return list(t) + list(Rotation.from_matrix(R).as_quat())        # scipy: x y z w
+
+
+def inverse3(m):
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_quat(np.asarray(m[3:7]) / np.linalg.norm(m[3:7])).as_matrix()
+    return list(-(R.T @ np.asarray(m[:3]))) + list(Rotation.from_matrix(R.T).as_quat())
+
+
+def main3():
+    """The same three duplicates on the SE3 fixture (thresholds of bash/ipc_experiments_3D.sh: s = 50, 6.251 / 6.251)."""
+    global PRM
+    PRM = (50.0, 6.251, 50, 6.251, 100)
+    g = graphio.read_g2o(os.path.join(HERE, "small_se3_spoiled_n5_seed4.g2o"))
+    inc, order, dec = run(g)
+    accepted = {int(k) for k, d in zip(order, dec) if d}
+    true_loop, outlier, other = 1, 7, 2
+    assert true_loop in accepted and other in accepted and outlier not in accepted
+    P = inc.poses()
+    a, b = g.loop_ids[outlier]
+    ids = np.vstack([g.loop_ids, g.loop_ids[true_loop], g.loop_ids[outlier], g.loop_ids[other][::-1]]).astype(np.int32)
+    meas = np.vstack([g.loop_meas, g.loop_meas[outlier], rel_pose3(P[a], P[b]), inverse3(g.loop_meas[other])])
+    info = np.vstack([g.loop_info, g.loop_info[true_loop], g.loop_info[outlier], g.loop_info[other]])
+    g2 = graphio.PoseGraph(g.dim, g.vertices, g.odom_meas, g.odom_info, ids, meas, info)
+    graphio.write_g2o(os.path.join(HERE, "small_se3_dup_pairs.g2o"), g2)
+    g2 = graphio.read_g2o(os.path.join(HERE, "small_se3_dup_pairs.g2o"))
+    _, order2, dec2 = run(g2)
+    by_index = np.zeros(g2.N, dtype=np.uint8)
+    by_index[order2] = dec2
+    n = g.N
+    print("SE3 decisions by file index:", by_index, " A/B/C:", by_index[n], by_index[n + 1], by_index[n + 2])
+    assert by_index[true_loop] == 1 and by_index[n] == 0
+    assert by_index[outlier] == 0 and by_index[n + 1] == 1
+    np.savez_compressed(os.path.join(HERE, "small_se3_dup_pairs_expected.npz"), order=order2, decision=dec2,
+                        params=np.array(PRM), duplicates=np.array([[true_loop, n], [outlier, n + 1], [other, n + 2]]))
+
+
 def main():
     g = graphio.read_g2o(os.path.join(HERE, "small_se2_spoiled_n6_seed3.g2o"))
     inc, order, dec = run(g)
@@ -72,3 +114,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main3()

@@ -114,17 +114,18 @@ def test_adapter_with_candidates_that_are_not_in_the_graph(tmp_path, dim, spoile
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,stem", [(2, "small_se2_dup_pairs"), (3, "small_se3_dup_pairs")])
 @pytest.mark.parametrize("where", ["graph", "foreign"])
-def test_adapter_checks_the_edge_it_is_given_on_duplicate_vertex_pairs(tmp_path, where):
+def test_adapter_checks_the_edge_it_is_given_on_duplicate_vertex_pairs(tmp_path, where, dim, stem):
     """Three vertex pairs carry two candidates each, with different measurements and different verdicts
-    (tests/golden/make_dup_pair_golden.py): agreementCheck judges the object it is handed (src/consensus.cpp:43-56),
-    not an earlier candidate on the same pair.  Expected decisions: the CPU oracle's (committed fixture)."""
+    (tests/golden/make_dup_pair_golden.py, SE2 and SE3): agreementCheck judges the object it is handed
+    (src/consensus.cpp:43-56), not an earlier candidate on the same pair.  Expected decisions: the CPU oracle's (committed fixture)."""
     from ipc_amd import graphio
-    path = os.path.join(GOLD, "small_se2_dup_pairs.g2o")
-    exp = np.load(os.path.join(GOLD, "small_se2_dup_pairs_expected.npz"))
-    prm = _prm(2)
+    path = os.path.join(GOLD, stem + ".g2o")
+    exp = np.load(os.path.join(GOLD, stem + "_expected.npz"))
+    prm = _prm(dim)
     g = graphio.read_g2o(path)
-    lines = _run_adapter(tmp_path, 2, path, prm, order="stable", where=where)
+    lines = _run_adapter(tmp_path, dim, path, prm, order="stable", where=where)
     called = [int(x) for x in lines["order"].split()]
     assert called == list(exp["order"])
     got = [int(x) for x in lines["decisions"].split()]
@@ -133,7 +134,7 @@ def test_adapter_checks_the_edge_it_is_given_on_duplicate_vertex_pairs(tmp_path,
     for first, second in exp["duplicates"]:
         assert tuple(sorted(g.loop_ids[first])) == tuple(sorted(g.loop_ids[second]))
     assert [by_index[int(a)] != by_index[int(b)] for a, b in exp["duplicates"][:2]] == [True, True]
-    lines = _run_adapter(tmp_path, 2, path, prm, order="ref", where=where)
+    lines = _run_adapter(tmp_path, dim, path, prm, order="ref", where=where)
     called = [int(x) for x in lines["order"].split()]
     assert [int(x) for x in lines["decisions"].split()] == _python_path(g, prm, called)
 
