@@ -257,21 +257,21 @@ constexpr int kPlanSub = 32;
 // sorted by chain position.  The cell kernels draw cells from the head of the list, so the cells in flight at any moment
 // are neighbours along the trajectory and their chain records are shared through L2 (C5, 21.6 MB of records against
 // 4 MB of L2 per XCD: round 3 fetched every record from beyond L2 in every pass, 35.8x the algorithmic bytes).  Blocks
-// that run side by side (consecutive u) land in different chunks, i.e. on different counters.
-__global__ void k_plan(int N, const int* lo, const int* hi, int rank, int rpr, const int* rowslot, const int* rowperm, BinCaps bc,
+// that run side by side (consecutive u) land in different chunks, i.e. on different counters.  `rowperm` lists the rows of
+// the calling rank only (ensure_row_map: rank-major groups, each sorted by first vertex).
+__global__ void k_plan(int N, const int* lo, const int* hi, const int* rowperm, int nrows, BinCaps bc,
                        unsigned* counters, const unsigned* offsets, int2* cells, int fill, int phase = 0,
                        const unsigned long long* diag = nullptr, int words = 0)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;          // this thread's candidate, its interval read once
     const int loj = j < N ? lo[j] : 0, hij = j < N ? hi[j] : 0;
     const bool alivej = phase != 2 || (j < N && ((diag[(size_t)j * words + (j >> 6)] >> (j & 63)) & 1ull));
-    const int chunk = (N + kPlanSub - 1) / kPlanSub;
+    const int chunk = (nrows + kPlanSub - 1) / kPlanSub;
     for (int u = blockIdx.y; u < chunk * kPlanSub; u += gridDim.y) {
     const int sub = u & (kPlanSub - 1);
     const int q = sub * chunk + (u / kPlanSub);                   // position in the row order
-    if (q >= N || (u / kPlanSub) >= chunk) continue;
-    const int i = rowperm[q];
-    if (rowslot[i] / rpr != rank) continue;                       // rows of this rank (ipc_row_assignment)
+    if (q >= nrows || (u / kPlanSub) >= chunk) continue;
+    const int i = rowperm[q];                                     // (the rows of THIS rank only: the pass costs 1 / world of the matrix's rows)
     if (phase == 2 && !((diag[(size_t)i * words + (i >> 6)] >> (i & 63)) & 1ull)) continue;
     if ((int)((blockIdx.x + 1) * blockDim.x) <= i) continue;       // this block's candidates all precede row i (j < i)
     int slot = -1;
@@ -564,7 +564,8 @@ struct ipc_engine {
     double* d_cand = nullptr; int cstride = 0;        // cstride = capacity in records (>= N): the list grows in place
     int *d_from = nullptr, *d_to = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_order = nullptr;
     int* d_live = nullptr;                             // set-max: candidates with a set diagonal bit, in processing order
-    int* d_rowperm = nullptr;                          // rows in the order the planning pass visits them (by first vertex, then index)
+    int* d_rowperm = nullptr;                          // rows grouped by owning rank (of slot_world), each group in the order the planning pass visits them (by first vertex, then index)
+    std::vector<int> row_group_off;                    // [world + 1] offsets of the groups
     bool order_stale = false;                          // d_order is behind `order` (appends): re-sent by the next matrix-mode call
     std::vector<void*> retired;                        // candidate arrays a growth replaced while solves in flight may still read them
     hipEvent_t ev_cand = nullptr; bool cand_event = false;   // behind the last record written by ipc_append_candidate (own_stream)
@@ -980,15 +981,6 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     return IPC_OK;
 }
 
-// the order in which the planning pass visits the rows: by the first vertex of the candidate's interval, then by index
-static int upload_row_order(ipc_engine* h)
-{
-    std::vector<int> perm(h->N);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return h->h_lo[a] < h->h_lo[b]; });
-    HIPCHK(hipMemcpy(h->d_rowperm, perm.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
-    return IPC_OK;
-}
 
 // Uploads the candidate list (file order); the consensus set and the current poses go back to the open-loop state.
 static int upload_candidates(ipc_engine* h, int n, const int* ids, const double* meas, const double* info)
@@ -1034,7 +1026,6 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     HIPCHK(hipMemcpy(h->d_lo, h->h_lo.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_hi, h->h_hi.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_order, h->order.data(), sizeof(int) * n, hipMemcpyHostToDevice));
-    if (int rc = upload_row_order(h)) return rc;
     double *d_m = nullptr, *d_i = nullptr;
     HIPCHK(hipMalloc(&d_m, sizeof(double) * ms * n));
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * n));
@@ -1122,7 +1113,6 @@ static int matrix_mode_enter(ipc_engine* h, hipStream_t st)
     if (h->order_stale && h->N > 0) {
         HIPCHK(hipMemcpyAsync(h->d_order, h->order.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));     // (pageable source: the copy has left the host vector when this returns)
-        if (int rc = upload_row_order(h)) return rc;
         h->order_stale = false;
     }
     if (h->cand_event && st != h->own_stream) HIPCHK(hipStreamWaitEvent(st, h->ev_cand, 0));
@@ -1278,6 +1268,19 @@ static int ensure_row_map(ipc_engine* h, int world)
     if (int rc = ipc_row_assignment(h->N, h->h_cand_ids.data(), world, h->row_policy, slot.data())) return rc;
     if (!h->d_slot) HIPCHK(hipMalloc(&h->d_slot, sizeof(int) * h->N));
     HIPCHK(hipMemcpy(h->d_slot, slot.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+    // the rows of each rank, in the order its planning pass visits them: by the first vertex of the candidate's interval,
+    // then by index (cell lists sorted by chain position, see k_plan)
+    const int rpr = ipc_rows_per_rank(h->N, world);
+    std::vector<int> perm(h->N);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        const int ra = slot[a] / rpr, rb = slot[b] / rpr;
+        return ra != rb ? ra < rb : h->h_lo[a] < h->h_lo[b];
+    });
+    h->row_group_off.assign(world + 1, 0);
+    for (int i = 0; i < h->N; ++i) ++h->row_group_off[slot[i] / rpr + 1];
+    for (int r = 0; r < world; ++r) h->row_group_off[r + 1] += h->row_group_off[r];
+    HIPCHK(hipMemcpy(h->d_rowperm, perm.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
     h->slot_world = world;
     return IPC_OK;
 }
@@ -1383,8 +1386,10 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     if (phase != 2) HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
     // pass 1: count
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    const dim3 pgrid((N + 255) / 256, std::min(N, 2048)), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, (const int*)h->d_rowperm, bc, h->d_counters,
+    const int nrows = h->row_group_off[rank + 1] - h->row_group_off[rank];
+    const int* rows = h->d_rowperm + h->row_group_off[rank];
+    const dim3 pgrid((N + 255) / 256, std::max(1, std::min(nrows, 2048))), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
                        h->d_offsets, (int2*)nullptr, 0, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
@@ -1416,7 +1421,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     // pass 2: fill
     HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rank, rpr, (const int*)h->d_slot, (const int*)h->d_rowperm, bc, h->d_counters,
+    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
                        h->d_offsets, h->d_cells, 1, phase, (const unsigned long long*)d_upper, words);
     HIPCHK(hipGetLastError());
     // solve: longest chains first

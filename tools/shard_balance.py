@@ -10,6 +10,8 @@ from ipc_amd.dist import EngineBackend
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 worlds = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
+if worlds[0] != 1:
+    worlds = [1] + worlds                             # (the speed-up is quoted against the one-rank step)
 g, cfg, desc = build_workload(wl)
 eng = IPC(g, cfg, device=0)
 b = EngineBackend(eng)
