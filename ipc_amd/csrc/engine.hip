@@ -667,6 +667,12 @@ struct ipc_engine {
     bool window_forced = false;                        // IPC_SPEC_WINDOW given: taken as is, no probe
     int stream_concurrency = 0;                        // streams of the window measured to run side by side (diagnostic)
     double accept_rate = 0.5;                          // running mean over the recent verdicts: how far ahead it pays to assume "reject"
+    // Predicted verdicts (scheduling only, never a decision): a solve behind a candidate that is expected to be accepted
+    // and whose verdict is still out will most likely be thrown away, so at most spec_behind of them are started; in
+    // front of it everything in flight is useful and the window may be as wide as the CUs allow.
+    std::vector<char> pred_accept;                     // by candidate: 1 = expected to be accepted
+    int spec_behind = 4;                               // IPC_SPEC_BEHIND
+    double gate_release_ms = 0.0;                      // a predicted accept still running after this long counts as a reject (0: 2.5 x the mean accepted solve)
     int helper_limit = 39;
     double st_acc_s = 0, st_rej_s = 0; long st_acc_it = 0, st_rej_it = 0, st_acc_n = 0, st_rej_n = 0;   // IPC_SPEC_STATS
     unsigned long long commit_count = 0;
@@ -684,6 +690,15 @@ static int spec_quiesce(ipc_engine* h, bool state_changes);
 static ipc_engine* g_active_pipeline = nullptr;
 static std::mutex g_pipeline_mu;                       // (engines of different host threads: ipc_run_sharded, callers with one engine per thread)
 
+// Device-to-device copy the host can rely on when it returns.  (hipMemcpy of this kind goes to the NULL stream and is not
+// complete -- not even submitted, as it turned out -- when the call returns; the engine's streams are non-blocking, so a
+// solve enqueued right behind it could read the buffer before the copy: round 4, a faithful run that started from the
+// previous run's poses once in a dozen repetitions.)
+static hipError_t copy_d2d_now(ipc_engine* h, void* dst, const void* src, size_t bytes)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->own_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->own_stream);
+}
 extern "C" int ipc_rows_per_rank(int n, int world) { return world > 0 ? (n + world - 1) / world : 0; }
 
 // Which rank solves which row, and where the row sits in that rank's shard: slot[i] = owner * rpr + index, rpr =
@@ -764,6 +779,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         if (*pp && strcmp(pp, "0")) {
             if (hipMalloc(&h->d_prof, sizeof(unsigned long long) * kProfN) != hipSuccess) h->d_prof = nullptr;
             else hipMemset(h->d_prof, 0, sizeof(unsigned long long) * kProfN);
+            hipStreamSynchronize(nullptr);                             // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
         }
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
@@ -789,6 +805,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) { h->spec_window = std::max(1, std::min(32, atoi(sw))); h->window_forced = true; } }
     if (const char* sa = getenv("IPC_SPEC_AHEAD")) { if (*sa) h->spec_ahead = std::max(1, std::min(1024, atoi(sa))); }
+    if (const char* sb = getenv("IPC_SPEC_BEHIND")) { if (*sb) h->spec_behind = std::max(0, std::min(64, atoi(sb))); }
+    if (const char* gr = getenv("IPC_SPEC_GATE_MS")) { if (*gr) h->gate_release_ms = std::max(0.0, atof(gr)); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
         else if (*cm && strcmp(cm, "persist")) { delete h; return fail(IPC_ERR_ARG, "IPC_CLUSTER_MODE must be 'persist' or 'host'"); }
@@ -827,6 +845,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * E));
     HIPCHK(hipMemcpy(d_m, odom_meas, sizeof(double) * ms * E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_i, odom_info, sizeof(double) * is * E, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     HIPCHK(hipMemsetAsync(h->d_chain, 0, sizeof(double) * (nf * (size_t)h->estride + 64), h->own_stream));
     if (dim == 2) {
         hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
@@ -1000,7 +1019,7 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     h->ev_valid = false;
     h->cns.clear();
     if (h->d_cur && h->d_open)
-        HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
+        HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V));
     const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
     h->h_cand_ids.assign(ids, ids + 2 * (size_t)n);                       // raw records (row assignment, appends)
     h->h_cand_meas.assign(meas, meas + (size_t)ms * n);
@@ -1031,6 +1050,7 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     HIPCHK(hipMalloc(&d_i, sizeof(double) * is * n));
     HIPCHK(hipMemcpy(d_m, meas, sizeof(double) * ms * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_i, info, sizeof(double) * is * n, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     if (h->dim == 2)
         hipLaunchKernelGGL(k_se2_prep, dim3((n + 255) / 256), dim3(256), 0, h->own_stream, n, d_m, d_i, 1.0,
                            h->d_cand, h->cstride);
@@ -1258,6 +1278,7 @@ static int solve_long_cells(ipc_engine* h, hipStream_t st, int nb, const unsigne
         HIPCHK(hipMemcpy(h->d_chitot + offsets[s], tot.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_meta + offsets[s], meta.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
     }
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     return IPC_OK;
 }
 
@@ -1281,6 +1302,7 @@ static int ensure_row_map(ipc_engine* h, int world)
     for (int i = 0; i < h->N; ++i) ++h->row_group_off[slot[i] / rpr + 1];
     for (int r = 0; r < world; ++r) h->row_group_off[r + 1] += h->row_group_off[r];
     HIPCHK(hipMemcpy(h->d_rowperm, perm.data(), sizeof(int) * h->N, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     h->slot_world = world;
     return IPC_OK;
 }
@@ -1356,6 +1378,7 @@ static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
         if (literal) ++h->last_literal_cells;
         else ++h->last_lm_cells;
     }
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     set_eps(h->term_eps);
     return IPC_OK;
 }
@@ -1783,7 +1806,7 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         if (!h->d_cur) {
             h->d_open = h->d_pose0;                   // same [12][V] layout; not owned twice, see ipc_destroy
             HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 12 * (size_t)h->V));
-            HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V, hipMemcpyDeviceToDevice));
+            HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V));
         }
         if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; h->cluster3->allow_damping = h->lm_retry; }
         if (!h->persist3) {
@@ -1830,7 +1853,7 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
     if (!h) return fail(IPC_ERR_ARG, "ipc_incremental_reset: NULL handle");
     if (int rc = ensure_incremental(h, "ipc_incremental_reset")) return rc;
     if (int rc = spec_quiesce(h, true)) return rc;
-    HIPCHK(hipMemcpy(h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V, hipMemcpyDeviceToDevice));
+    HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V));
     h->cns.clear();
     std::fill(h->handed.begin(), h->handed.end(), 0);
     h->porder = h->order;
@@ -2227,24 +2250,35 @@ static int spec_pump(ipc_engine* h)
     }
     // How many solves to keep in flight: the j-th one beyond the first unknown verdict is of use only if the j before it
     // all reject -- (1 - accept rate)^j; below 5 % it is not started (3 in flight at 70 % accepts, the whole window at 13 %).
+    const bool predicting = !h->pred_accept.empty();
     int target = B;
-    if (h->accept_rate > 0.01) {
+    if (!predicting && h->accept_rate > 0.01) {
         const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
         target = std::max(2, std::min(target, 1 + (int)r));
     }
+    const double release_ms = h->gate_release_ms > 0.0 ? h->gate_release_ms
+                              : (h->st_acc_n >= 8 ? std::max(1.0, 2.5e3 * h->st_acc_s / (double)h->st_acc_n) : 8.0);
+    const auto now = std::chrono::steady_clock::now();
     // the positions to launch: lowest first, the ones from the head on that have neither a parked result nor a solve in flight
     const int end = std::min(h->N, h->spec_head + h->spec_ahead);
+    bool gated = false;                                // a predicted accept with its verdict still out lies in front of lp
+    int behind = 0;                                    // solves in flight behind it
     for (int lp = h->spec_head; lp < end; ++lp) {
         if (h->spec_res[lp].valid) continue;
-        int q = -1, running = 0, busy = 0;
-        bool in_flight = false;
+        int q = -1, running = 0, busy = 0, at = -1;
         for (int i = 0; i < B; ++i) {
             running += h->slots[i].cand >= 0;
-            in_flight = in_flight || (h->slots[i].cand >= 0 && h->slots[i].pos == lp);
+            if (h->slots[i].cand >= 0 && h->slots[i].pos == lp) at = i;
             if (h->slots[i].cand < 0 && (q < 0 || (h->slots[q].busy_wgs && !h->slots[i].busy_wgs))) q = i;   // (an empty stream first)
         }
-        if (in_flight) continue;
+        const bool pa = predicting && h->pred_accept[h->porder[lp]];
+        if (at >= 0) {
+            if (gated) ++behind;
+            else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) gated = true;
+            continue;
+        }
         if (q < 0 || running >= target) break;
+        if (gated && behind >= h->spec_behind) break;
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
@@ -2254,6 +2288,8 @@ static int spec_pump(ipc_engine* h)
         const int tip = spec_state_at(h, lp);
         if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) break;
         if (int rc = spec_launch(h, q, lp, std::max(0, helpers))) return rc;
+        if (gated) ++behind;
+        else if (pa) gated = true;
     }
     return IPC_OK;
 }
@@ -2290,6 +2326,13 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
         if (int rc = spec_reset(h)) return rc;
         if (int rc = spec_adopt_current(h)) return rc;
         h->spec_res.assign(h->N, ipc_engine::SpecResult{});
+        if (const char* pf = getenv("IPC_SPEC_PREDICT_FILE")) {          // (experiments: the verdicts of a recorded run as the prediction)
+            if (FILE* f = *pf ? fopen(pf, "r") : nullptr) {
+                h->pred_accept.assign(h->N, 0);
+                for (int c = 0; c < h->N; ++c) { const int ch = fgetc(f); if (ch == EOF) break; h->pred_accept[c] = ch == '1'; }
+                fclose(f);
+            }
+        }
         // the candidates already handed out in front of the head, the others behind it, both in the order they have
         std::stable_partition(h->porder.begin(), h->porder.end(), [&](int c) { return h->handed[c] != 0; });
         h->spec_head = 0;
@@ -2488,6 +2531,7 @@ extern "C" int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int 
         HIPCHK(hipMalloc(&d_i, sizeof(double) * is * E));
         HIPCHK(hipMemcpy(d_m, h->h_odom_meas.data(), sizeof(double) * ms * E, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_i, h->h_odom_info.data(), sizeof(double) * is * E, hipMemcpyHostToDevice));
+        HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
         HIPCHK(hipMemsetAsync(h->d_chain1, 0, sizeof(double) * (nf * h->estride + 64), h->own_stream));
         if (h->dim == 2)
             hipLaunchKernelGGL(k_se2_prep, dim3((E + 255) / 256), dim3(256), 0, h->own_stream, E, d_m, d_i,
@@ -2544,6 +2588,7 @@ extern "C" int ipc_debug_dense_solve(int n, const double* system, int mode, int 
     HIPCHK(hipMemset(dA + m, 0, sizeof(double) * m));
     HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
     HIPCHK(hipMemset(dctl, 0, sizeof(PersistCtl)));
+    HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     if (mode == 0) {
         HIPCHK(chol_solve_device(dA, dA + m, n, dx, dinfo, nullptr));
     } else {

@@ -29,13 +29,18 @@ def main():
         eng.reset()
         h = hashlib.sha256()
         it = tr = acc = 0
+        rows = []
         t0 = time.perf_counter()
         for k in order:
             ok, info = eng.agreementCheck(k, with_info=True)
+            rows.append((k, ok, info.iterations, info.tries, info.max_chi2, info.n_cluster_loops, info.lo, info.hi, info.chi2_initial))
             h.update(np.array([ok, info.iterations, info.tries], dtype=np.int64).tobytes())
             h.update(np.float64(info.max_chi2).tobytes())
             it += info.iterations; tr += info.tries; acc += ok
         best = min(best, time.perf_counter() - t0)
+        if os.environ.get("IPC_DUMP_RUN"):             # per-candidate records of every repetition (to find where two runs part)
+            np.save(os.environ["IPC_DUMP_RUN"] + ".rep%d.npy" % _, np.array(rows, dtype=np.float64))
+            print("   rep", _, h.hexdigest()[:16], flush=True)
     print("%-28s %-4s %8.3f s  %7.1f candidates/s  accepted %d iterations %d tries %d digest %s" % (
         os.path.basename(lib), which, best, g.N / best, acc, it, tr, h.hexdigest()[:16]), flush=True)
     eng.close()
