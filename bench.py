@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before HIP initialises: one hardware queue per solve of the incremental mode's window
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # before HIP initialises: one hardware queue per solve of the incremental mode's window
 
 import numpy as np
 import torch

@@ -644,6 +644,9 @@ struct ipc_engine {
         int pos = -1;                                  // the accept at this processing position on top of its parent
         int users = 0;                                 // solves in flight that read it
         bool live = false;                             // committed, or in the tentative chain
+        // predictions: every candidate's own chi2 at these poses (k_cand_own_chi2), copied to pinned host memory
+        double* d_pred = nullptr; double* h_pred = nullptr; int pred_cap = 0, pred_n = 0;
+        hipEvent_t pred_ev = nullptr; bool has_pred = false, pred_ready = false;
     };
     struct SpecResult {                                // a finished solve waiting for its candidate's turn
         bool valid = false, agree = false, retry_host = false;
@@ -670,8 +673,13 @@ struct ipc_engine {
     // Predicted verdicts (scheduling only, never a decision): a solve behind a candidate that is expected to be accepted
     // and whose verdict is still out will most likely be thrown away, so at most spec_behind of them are started; in
     // front of it everything in flight is useful and the window may be as wide as the CUs allow.
-    std::vector<char> pred_accept;                     // by candidate: 1 = expected to be accepted
+    std::vector<char> pred_accept;                     // by candidate: 1 = expected to be accepted (IPC_SPEC_PREDICT_FILE: a recorded run, experiments)
+    double pred_k = 10.0;                              // predicted accept: own chi2 at the state it starts from <= pred_k x the slow threshold (IPC_SPEC_PREDICT; 0: off)
+    std::vector<double> pred_last;                     // the newest predictions that have arrived (stand-in while a state's own are on their way)
     int spec_behind = 4;                               // IPC_SPEC_BEHIND
+    int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
+                                                       // the rejects are the bulk of the work and independent of each other -- many of them
+                                                       // side by side; the expected accepts are the serial chain -- each as fast as it can be
     double gate_release_ms = 0.0;                      // a predicted accept still running after this long counts as a reject (0: 2.5 x the mean accepted solve)
     int helper_limit = 39;
     double st_acc_s = 0, st_rej_s = 0; long st_acc_it = 0, st_rej_it = 0, st_acc_n = 0, st_rej_n = 0;   // IPC_SPEC_STATS
@@ -755,7 +763,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     // The speculative window of the faithful mode runs one persistent launch per stream; streams that share a hardware
     // queue run their kernels one after the other, and the runtime's default is 4 queues.  Only effective when this is
     // the process's first HIP call (otherwise export GPU_MAX_HW_QUEUES before starting; ipc_amd/capi.py does).
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(IPC_ERR_ARG, "ipc_create: device %d of %d", device, ndev);
@@ -801,10 +809,12 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     {   // window: as many solves in flight as there are hardware queues to run them side by side (IPC_SPEC_WINDOW overrides)
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         const int nq = q ? atoi(q) : 4;
-        h->spec_window = nq >= 13 ? 10 : (nq >= 9 ? 8 : 4);          // (+ the engine's own stream and its two side streams)
+        h->spec_window = nq >= 24 ? 16 : (nq >= 13 ? 10 : (nq >= 9 ? 8 : 4));          // (+ the engine's own stream and its two side streams)
     }
     if (const char* sw = getenv("IPC_SPEC_WINDOW")) { if (*sw) { h->spec_window = std::max(1, std::min(32, atoi(sw))); h->window_forced = true; } }
     if (const char* sa = getenv("IPC_SPEC_AHEAD")) { if (*sa) h->spec_ahead = std::max(1, std::min(1024, atoi(sa))); }
+    if (const char* pk = getenv("IPC_SPEC_PREDICT")) { if (*pk) h->pred_k = std::max(0.0, atof(pk)); }
+    if (const char* hr = getenv("IPC_PERSIST_HELPERS_REJECT")) { if (*hr) h->helper_limit_reject = std::max(0, atoi(hr)); }
     if (const char* sb = getenv("IPC_SPEC_BEHIND")) { if (*sb) h->spec_behind = std::max(0, std::min(64, atoi(sb))); }
     if (const char* gr = getenv("IPC_SPEC_GATE_MS")) { if (*gr) h->gate_release_ms = std::max(0.0, atof(gr)); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
@@ -972,6 +982,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     for (auto& stt : h->spec_states) {
         if (stt.owned) hipFree(stt.d_poses);
         if (stt.ready) hipEventDestroy(stt.ready);
+        if (stt.h_pred) hipHostFree(stt.h_pred);
+        if (stt.pred_ev) hipEventDestroy(stt.pred_ev);
     }
     if (h->d_prof || getenv("IPC_SPEC_STATS"))
         fprintf(stderr, "{\"speculation\": {\"window\": %d, \"streams_abreast\": %d, \"persist_timeouts\": %ld, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
@@ -1733,6 +1745,34 @@ __global__ void k_se3_propagate_tail(int V, int start, const double* rec, int st
     }
 }
 
+// A candidate's OWN chi2 at a pose state ([5 | 12][V]), every candidate of the engine at once: what the speculative
+// pipeline predicts verdicts from (spec_pump).  Scheduling only -- no decision ever depends on it.
+__global__ void k_cand_own_chi2_se2(const double* poses, int V, const double* cand, int cstride, const int* from, const int* to,
+                                    int n, double* out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int ia = from[c], ib = to[c];
+    const Pose2 a{poses[ia], poses[V + ia], poses[2 * (size_t)V + ia], poses[3 * (size_t)V + ia], poses[4 * (size_t)V + ia]};
+    const Pose2 b{poses[ib], poses[V + ib], poses[2 * (size_t)V + ib], poses[3 * (size_t)V + ib], poses[4 * (size_t)V + ib]};
+    double e0, e1, e2;
+    se2_error(a, b, cand[(size_t)F_TZX * cstride + c], cand[(size_t)F_TZY * cstride + c], cand[(size_t)F_CZ * cstride + c],
+              cand[(size_t)F_SZ * cstride + c], cand[(size_t)F_THZ * cstride + c], e0, e1, e2);
+    out[c] = gk_sym(cand, cstride, F_OM, c).quad(e0, e1, e2);
+}
+__global__ void k_cand_own_chi2_se3(const double* poses, int V, const double* cand, int cstride, const int* from, const int* to,
+                                    int n, double* out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double Rz[9], tz[3], om[21];
+    gk3_rz(cand, cstride, c, Rz, tz);
+    Edge3 E;
+    se3_edge(gk3_pose(poses, V, from[c]), gk3_pose(poses, V, to[c]), Rz, tz, E);
+    gk3_sym(cand, cstride, G_OM, c, om);
+    out[c] = sym6_quad(om, E.e);
+}
+
 // The accept branch of IPC::agreementCheck (src/consensus.cpp:69-71) in one launch: dst = parent outside the window, the
 // optimised poses inside lo..hi, then propagateCurrentGuess (consensus_utils.cpp:61-71) down the tail.  The reference
 // composes the tail pose by pose, v[i] = v[i-1] (+) z[i-1]; since every pose behind hi is then pure odometry on top of
@@ -1988,6 +2028,7 @@ static int spec_alloc_state(ipc_engine* h, int& idx)
         // (a dropped state's poses may still be on their way -- copies queued on the stream of the solve that made it:
         // they would land on top of the new owner's)
         if (c.has_ready && hipEventQuery(c.ready) != hipSuccess) continue;
+        if (c.has_pred && !c.pred_ready && hipEventQuery(c.pred_ev) != hipSuccess) continue;     // (its prediction kernel still reads them)
         idx = (int)i;
         break;
     }
@@ -2000,7 +2041,7 @@ static int spec_alloc_state(ipc_engine* h, int& idx)
         HIPCHK(hipEventCreateWithFlags(&n.ready, hipEventDisableTiming));
     }
     ipc_engine::SpecState& n = h->spec_states[idx];
-    n.live = true; n.users = 0; n.pos = -1; n.has_ready = false; n.cns.clear();
+    n.live = true; n.users = 0; n.pos = -1; n.has_ready = false; n.has_pred = n.pred_ready = false; n.cns.clear();
     return IPC_OK;
 }
 
@@ -2052,7 +2093,37 @@ static int spec_adopt_current(ipc_engine* h)
     }
     ipc_engine::SpecState& c = h->spec_states[idx];
     c.live = true; c.pos = -1; c.cns = h->cns; c.has_ready = false;      // (its readers wait for ev_commit instead)
+    c.has_pred = c.pred_ready = false;
     h->committed_state = idx;
+    return IPC_OK;
+}
+
+// Every candidate's own chi2 at the poses of state `si`, enqueued on `st` (behind whatever completes those poses), written
+// straight into host-mapped memory; S.pred_ev says when they are there.
+static int spec_predict_state(ipc_engine* h, int si, hipStream_t st)
+{
+    ipc_engine::SpecState& S = h->spec_states[si];
+    S.has_pred = S.pred_ready = false;
+    if (!(h->pred_k > 0.0) || h->N == 0) return IPC_OK;
+    if (S.pred_cap < h->N) {
+        if (S.h_pred) HIPCHK(hipHostFree(S.h_pred));
+        S.h_pred = nullptr;
+        S.pred_cap = std::max(1024, 2 * h->N);
+        HIPCHK(hipHostMalloc(&S.h_pred, sizeof(double) * S.pred_cap, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&S.d_pred), S.h_pred, 0));
+    }
+    if (!S.pred_ev) HIPCHK(hipEventCreateWithFlags(&S.pred_ev, hipEventDisableTiming));
+    if (h->cand_event) HIPCHK(hipStreamWaitEvent(st, h->ev_cand, 0));
+    S.pred_n = h->N;
+    if (h->dim == 3)
+        hipLaunchKernelGGL(k_cand_own_chi2_se3, dim3((h->N + 127) / 128), dim3(128), 0, st, (const double*)S.d_poses, h->V,
+                           (const double*)h->d_cand, h->cstride, (const int*)h->d_from, (const int*)h->d_to, h->N, S.d_pred);
+    else
+        hipLaunchKernelGGL(k_cand_own_chi2_se2, dim3((h->N + 127) / 128), dim3(128), 0, st, (const double*)S.d_poses, h->V,
+                           (const double*)h->d_cand, h->cstride, (const int*)h->d_from, (const int*)h->d_to, h->N, S.d_pred);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(S.pred_ev, st));
+    S.has_pred = true;
     return IPC_OK;
 }
 
@@ -2061,7 +2132,7 @@ struct SpecTimer {
     explicit SpecTimer(double& a) : acc(a) {}
     ~SpecTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-static int spec_launch(ipc_engine* h, int q, int p, int helpers)
+static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_reject)
 {
     SpecTimer tm(h->spec_t_launch);
     ipc_engine::SpecSlot& sl = h->slots[q];
@@ -2078,6 +2149,12 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers)
     else if (!S.owned && h->commit_count) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_commit, 0));
     ++S.users;
     ++h->spec_launches;
+    if (expect_reject) {
+        // an expected reject gets a share of the helpers its system could use (one per two 64 x 64 tiles of the first trailing
+        // update is what an expected accept gets): 8 of 18 on C2's 480 unknowns, the full 39 on an SE3 cluster of 1 464
+        const int n = (h->dim == 2 ? 3 : 6) * (int)c.members.size(), nt = (n + 63) / 64, wanted = (nt * (nt + 1) / 2 + kPSG - 1) / kPSG;
+        helpers = std::min(helpers, std::max(h->helper_limit_reject, (int)(0.45 * wanted)));
+    }
     if (h->dim == 3) sl.s3->max_helpers = helpers; else sl.s2->max_helpers = helpers;
     if (h->dim == 3) {
         sl.s3->launch_id = sl.launch_id;
@@ -2118,6 +2195,7 @@ static int spec_make_tentative(ipc_engine* h, int p, int q)
     }
     HIPCHK(hipEventRecord(T.ready, sl.st));
     T.has_ready = true;
+    if (int rc = spec_predict_state(h, t, sl.st)) return rc;
     T.cns = P.cns;
     T.cns.push_back(h->porder[p]);
     T.pos = p;
@@ -2250,7 +2328,21 @@ static int spec_pump(ipc_engine* h)
     }
     // How many solves to keep in flight: the j-th one beyond the first unknown verdict is of use only if the j before it
     // all reject -- (1 - accept rate)^j; below 5 % it is not started (3 in flight at 70 % accepts, the whole window at 13 %).
-    const bool predicting = !h->pred_accept.empty();
+    const bool file_pred = !h->pred_accept.empty();
+    const bool predicting = file_pred || h->pred_k > 0.0;
+    const double pred_th = h->pred_k * h->prm.slow_reject_th;
+    // the predictions that hold at a position: those of the state a solve there starts from, or of the nearest state in
+    // front of it whose predictions have arrived (a candidate's own chi2 moves little from one state to the next)
+    auto preds_of = [&](int si, int& n) -> const double* {
+        ipc_engine::SpecState& S = h->spec_states[si];
+        if (!S.has_pred) return nullptr;
+        if (!S.pred_ready) { if (hipEventQuery(S.pred_ev) != hipSuccess) return nullptr; S.pred_ready = true; }
+        n = S.pred_n;
+        return S.h_pred;
+    };
+    int cur_n = 0;
+    const double* cur_pred = file_pred || !predicting ? nullptr : preds_of(h->committed_state, cur_n);
+    size_t ti = 0;
     int target = B;
     if (!predicting && h->accept_rate > 0.01) {
         const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
@@ -2262,6 +2354,8 @@ static int spec_pump(ipc_engine* h)
     // the positions to launch: lowest first, the ones from the head on that have neither a parked result nor a solve in flight
     const int end = std::min(h->N, h->spec_head + h->spec_ahead);
     bool gated = false;                                // a predicted accept with its verdict still out lies in front of lp
+    int gate_hi = -1;                                  // its later vertex: the candidates that END there too may be asked for before it (cmpTime
+                                                       // leaves their order open, src/utils.cpp:379-389), so they are not "behind" it
     int behind = 0;                                    // solves in flight behind it
     for (int lp = h->spec_head; lp < end; ++lp) {
         if (h->spec_res[lp].valid) continue;
@@ -2271,25 +2365,34 @@ static int spec_pump(ipc_engine* h)
             if (h->slots[i].cand >= 0 && h->slots[i].pos == lp) at = i;
             if (h->slots[i].cand < 0 && (q < 0 || (h->slots[q].busy_wgs && !h->slots[i].busy_wgs))) q = i;   // (an empty stream first)
         }
-        const bool pa = predicting && h->pred_accept[h->porder[lp]];
+        while (!file_pred && predicting && ti < h->tent.size() && h->spec_states[h->tent[ti]].pos < lp) {
+            int n2 = 0;
+            if (const double* p2 = preds_of(h->tent[ti], n2)) { cur_pred = p2; cur_n = n2; }
+            ++ti;
+        }
+        const int cand_lp = h->porder[lp];
+        const bool pa = file_pred ? h->pred_accept[cand_lp] != 0 : (cur_pred && cand_lp < cur_n && cur_pred[cand_lp] <= pred_th);
+        const bool tied = gated && h->h_hi[cand_lp] == gate_hi;
         if (at >= 0) {
-            if (gated) ++behind;
-            else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) gated = true;
+            if (gated) behind += !tied;
+            else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) { gated = true; gate_hi = h->h_hi[cand_lp]; }
             continue;
         }
         if (q < 0 || running >= target) break;
-        if (gated && behind >= h->spec_behind) break;
+        if (gated && !tied && behind >= h->spec_behind) break;
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
         for (int i = 0; i < B; ++i) if (i != q) busy += h->slots[i].busy_wgs;
+        // (an expected reject with next to nothing beside it -- a caller that appends one candidate per check -- is the critical path too)
+        const bool expect_reject = (cur_pred || file_pred) && !pa && running >= 4;
         const int helpers = std::min(h->helper_limit, h->n_cu - 8 - busy - 1);
         if (helpers < std::min(8, h->helper_limit) && running > 0) break;                     // (wait for a solve to leave)
         const int tip = spec_state_at(h, lp);
         if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) break;
-        if (int rc = spec_launch(h, q, lp, std::max(0, helpers))) return rc;
-        if (gated) ++behind;
-        else if (pa) gated = true;
+        if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject)) return rc;
+        if (gated) behind += !tied;
+        else if (pa) { gated = true; gate_hi = h->h_hi[cand_lp]; }
     }
     return IPC_OK;
 }
@@ -2325,6 +2428,8 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
     if (h->spec_head < 0) {                            // first call (or after a reset): the pipeline starts from the poses as they are
         if (int rc = spec_reset(h)) return rc;
         if (int rc = spec_adopt_current(h)) return rc;
+        if (int rc = spec_predict_state(h, h->committed_state, h->own_stream)) return rc;     // (own_stream: behind the last commit)
+        if (h->pred_k > 0.0) HIPCHK(hipStreamSynchronize(h->own_stream));
         h->spec_res.assign(h->N, ipc_engine::SpecResult{});
         if (const char* pf = getenv("IPC_SPEC_PREDICT_FILE")) {          // (experiments: the verdicts of a recorded run as the prediction)
             if (FILE* f = *pf ? fopen(pf, "r") : nullptr) {

@@ -15,5 +15,5 @@ for cfg in $1; do
   IFS=: read q w b hp <<< "$cfg"
   echo "== queues $q window $w behind $b helpers $hp"
   GPU_MAX_HW_QUEUES=$q IPC_SPEC_WINDOW=$w IPC_SPEC_BEHIND=$b IPC_PERSIST_HELPERS=$hp IPC_SPEC_PREDICT_FILE=${PRED-/tmp/pred_c2.txt} IPC_SPEC_STATS=1 \
-    python tools/lib_incremental.py ipc_amd/libipc_amd.so C2 2 2>&1 | grep -v amdgpu.ids | cut -c1-420
+    python tools/lib_incremental.py ipc_amd/libipc_amd.so ${WL:-C2} 2 2>&1 | grep -v amdgpu.ids | cut -c1-420
 done
