@@ -676,7 +676,7 @@ struct ipc_engine {
     std::vector<char> pred_accept;                     // by candidate: 1 = expected to be accepted (IPC_SPEC_PREDICT_FILE: a recorded run, experiments)
     double pred_k = 10.0;                              // predicted accept: own chi2 at the state it starts from <= pred_k x the slow threshold (IPC_SPEC_PREDICT; 0: off)
     std::vector<double> pred_last;                     // the newest predictions that have arrived (stand-in while a state's own are on their way)
-    int spec_behind = 4;                               // IPC_SPEC_BEHIND
+    int spec_behind = 1;                               // IPC_SPEC_BEHIND (C1: 0.56 / 0.59 / 0.59 / 0.63 s with 0 / 1 / 2 / 4 -- every launch is host time on the accept chain; C2, C4m: within noise)
     int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
                                                        // the rejects are the bulk of the work and independent of each other -- many of them
                                                        // side by side; the expected accepts are the serial chain -- each as fast as it can be

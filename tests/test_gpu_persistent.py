@@ -264,6 +264,45 @@ def test_pipeline_is_bitwise_on_c1_clusters_of_253_loops():
         ew.close()
 
 
+@pytest.mark.parametrize("env", [dict(), dict(IPC_SPEC_PREDICT=0), dict(IPC_SPEC_PREDICT=1e9), dict(IPC_SPEC_BEHIND=0),
+                                 dict(IPC_PERSIST_HELPERS_REJECT=2, IPC_SPEC_GATE_MS=0.05)])
+def test_scheduling_by_predicted_verdicts_changes_no_bit(env):
+    """Round 4: the pipeline predicts each candidate's verdict from its own chi2 at the state it starts from (a device kernel
+    per pose state), starts few solves behind an expected accept, gives expected rejects a share of the helper workgroups
+    and keeps 16 solves in flight.  A prediction schedules; it never decides: with the predictor off, with every candidate
+    predicted accepted, with nothing allowed behind an expected accept, with two helpers per expected reject -- every check
+    of C1 (71 % accepted) returns the bits of the one-at-a-time run, in the processing order and off it."""
+    import bench
+    g, cfg, _ = bench.build_workload("C1")
+    e1 = _engine(g, cfg, "persist", IPC_SPEC_WINDOW=1)
+    ew = _engine(g, cfg, "persist", **env)
+    order = e1.candidate_order()
+    _assert_bitwise(_run(e1, order), _run(ew, order))
+    assert np.array_equal(e1.current_poses().view(np.uint64), ew.current_poses().view(np.uint64))
+    assert np.array_equal(e1.getMaxConsensusSet(), ew.getMaxConsensusSet())
+    scrambled = np.concatenate([order[::3], order[1::3][::-1], order[2::3]])
+    _assert_bitwise(_run(e1, scrambled), _run(ew, scrambled))
+    for e in (e1, ew):
+        e.close()
+
+
+def test_run_after_reset_starts_from_the_open_loop_poses_every_time():
+    """Regression (round 4): ipc_incremental_reset copied the open-loop poses with a device-to-device hipMemcpy, i.e. on
+    the NULL stream, which the engine's non-blocking streams do not wait for -- the first solves of the next run could read
+    the previous run's final poses (one repetition in a dozen, decisions equal, chi2 different).  Ten runs on one engine,
+    each straight after the reset: all bitwise equal."""
+    import bench
+    g, cfg, _ = bench.build_workload("C1")
+    e = _engine(g, cfg, "persist")
+    order = e.candidate_order()
+    ref = _run(e, order)
+    for rep in range(9):
+        e.reset()
+        e.agreementCheck(int(order[0]))                 # (leaves speculative solves and tentative states behind)
+        _assert_bitwise(ref, _run(e, order))
+    e.close()
+
+
 def test_pipeline_is_left_mid_run_for_other_entry_points():
     """A caller that stops asking after a few candidates leaves solves in flight and results parked; the final map, the
     matrix mode and a second run must not care (they share the GPU's CUs with nothing of the pipeline)."""
