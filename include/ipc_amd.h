@@ -20,11 +20,13 @@
  *     stream when other work, e.g. a collective, must be ordered with the call).
  *   - a handle is bound to one GPU and must not be used from two threads at once (the
  *     reference's IPC object is not re-entrant either).
- *   - environment: the faithful mode keeps up to 10 solves in flight, one per HIP stream; streams that share a hardware
- *     queue run one after the other and the runtime's default is 4 queues.  Export GPU_MAX_HW_QUEUES=16 before the
+ *   - environment: the faithful mode keeps up to 16 solves in flight, one per HIP stream; streams that share a hardware
+ *     queue run one after the other and the runtime's default is 4 queues.  Export GPU_MAX_HW_QUEUES=24 before the
  *     process's first HIP call for full speed (ipc_create sets it when it is unset, which only helps if ipc_create IS the
  *     first HIP call -- true for the testers; ipc_amd/capi.py exports it at import).  IPC_SPEC_STATS=1 prints how many
- *     of the engine's streams were measured to run side by side.
+ *     of the engine's streams were measured to run side by side.  The order in which the pipeline starts its solves
+ *     follows a prediction of each verdict (the candidate's own chi2 at the poses it starts from; IPC_SPEC_PREDICT,
+ *     INTEGRATION.md): predictions schedule, no result depends on them.
  */
 #ifndef IPC_AMD_H
 #define IPC_AMD_H
