@@ -2105,7 +2105,8 @@ static int spec_predict_state(ipc_engine* h, int si, hipStream_t st)
     ipc_engine::SpecState& S = h->spec_states[si];
     S.has_pred = S.pred_ready = false;
     if (!(h->pred_k > 0.0) || h->N == 0) return IPC_OK;
-    if (S.pred_cap < h->N) {
+    if (S.pred_cap < h->N) {                       // (candidates appended since: a kernel of the state's last life may still write the old array)
+        if (S.h_pred && S.pred_ev) HIPCHK(hipEventSynchronize(S.pred_ev));
         if (S.h_pred) HIPCHK(hipHostFree(S.h_pred));
         S.h_pred = nullptr;
         S.pred_cap = std::max(1024, 2 * h->N);
@@ -2371,7 +2372,8 @@ static int spec_pump(ipc_engine* h)
             ++ti;
         }
         const int cand_lp = h->porder[lp];
-        const bool pa = file_pred ? h->pred_accept[cand_lp] != 0 : (cur_pred && cand_lp < cur_n && cur_pred[cand_lp] <= pred_th);
+        const bool pa = file_pred ? (cand_lp < (int)h->pred_accept.size() && h->pred_accept[cand_lp] != 0)
+                                   : (cur_pred && cand_lp < cur_n && cur_pred[cand_lp] <= pred_th);
         const bool tied = gated && h->h_hi[cand_lp] == gate_hi;
         if (at >= 0) {
             if (gated) behind += !tied;
