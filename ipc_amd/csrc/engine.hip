@@ -690,6 +690,9 @@ struct ipc_engine {
     int next_launch_id = 1;
     long spec_hits = 0, spec_launches = 0, spec_wasted = 0, spec_tentative = 0, spec_promoted = 0;
     double spec_t_launch = 0, spec_t_tent = 0, spec_t_total = 0;   // host seconds (IPC_SPEC_STATS)
+    // IPC_SPEC_STATS: why slots stood empty, in slot x pump calls (the caller's thread spins on the pump, so this is time):
+    // [0] behind an expected accept, [1] look-ahead used up / no candidate left, [2] CU budget, [3] cluster beyond the persistent solver, [4] total slot-pumps
+    unsigned long long idle_why[5] = {0, 0, 0, 0, 0};
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
@@ -990,11 +993,14 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
                         "\"tentative_states\": %ld, \"promoted\": %ld, \"host_s_in_checks\": %.3f, \"host_s_launching\": %.3f, "
                         "\"host_s_tentative\": %.3f, "
                         "\"accept_solves\": %ld, \"accept_us_per_iteration\": %.1f, \"accept_ms_per_solve\": %.2f, "
-                        "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f}}\n",
+                        "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f, "
+                        "\"empty_slot_share\": {\"behind_an_expected_accept\": %.3f, \"no_candidate_within_the_look_ahead\": %.3f, \"cu_budget\": %.3f, \"cluster_too_large\": %.3f}}}\n",
                 h->spec_window, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
                 h->spec_t_total, h->spec_t_launch, h->spec_t_tent,
                 h->st_acc_n, 1e6 * h->st_acc_s / std::max(1L, h->st_acc_it), 1e3 * h->st_acc_s / std::max(1L, h->st_acc_n),
-                h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n));
+                h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n),
+                (double)h->idle_why[0] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[1] / std::max(1ull, h->idle_why[4]),
+                (double)h->idle_why[2] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[3] / std::max(1ull, h->idle_why[4]));
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
     if (h->h_abort) hipHostFree(h->h_abort);
     delete h->persist2;
@@ -2354,6 +2360,7 @@ static int spec_pump(ipc_engine* h)
     const auto now = std::chrono::steady_clock::now();
     // the positions to launch: lowest first, the ones from the head on that have neither a parked result nor a solve in flight
     const int end = std::min(h->N, h->spec_head + h->spec_ahead);
+    int why = 1;                                       // why the scan ended (idle_why)
     bool gated = false;                                // a predicted accept with its verdict still out lies in front of lp
     int gate_hi = -1;                                  // its later vertex: the candidates that END there too may be asked for before it (cmpTime
                                                        // leaves their order open, src/utils.cpp:379-389), so they are not "behind" it
@@ -2380,8 +2387,8 @@ static int spec_pump(ipc_engine* h)
             else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) { gated = true; gate_hi = h->h_hi[cand_lp]; }
             continue;
         }
-        if (q < 0 || running >= target) break;
-        if (gated && !tied && behind >= h->spec_behind) break;
+        if (q < 0 || running >= target) { why = -1; break; }
+        if (gated && !tied && behind >= h->spec_behind) { why = 0; break; }
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
@@ -2389,12 +2396,18 @@ static int spec_pump(ipc_engine* h)
         // (an expected reject with next to nothing beside it -- a caller that appends one candidate per check -- is the critical path too)
         const bool expect_reject = (cur_pred || file_pred) && !pa && running >= 4;
         const int helpers = std::min(h->helper_limit, h->n_cu - 8 - busy - 1);
-        if (helpers < std::min(8, h->helper_limit) && running > 0) break;                     // (wait for a solve to leave)
+        if (helpers < std::min(8, h->helper_limit) && running > 0) { why = 2; break; }        // (wait for a solve to leave)
         const int tip = spec_state_at(h, lp);
-        if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) break;
+        if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) { why = 3; break; }
         if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject)) return rc;
         if (gated) behind += !tied;
         else if (pa) { gated = true; gate_hi = h->h_hi[cand_lp]; }
+    }
+    {
+        int idle = 0;
+        for (int i = 0; i < B; ++i) idle += h->slots[i].cand < 0;
+        h->idle_why[4] += (unsigned long long)B;
+        if (idle > 0 && why >= 0) h->idle_why[why] += (unsigned long long)idle;
     }
     return IPC_OK;
 }
