@@ -45,7 +45,8 @@ struct PersistOut {                          // result record (device, copied to
     int iterations, tries, flags, evals;
     int x_sel;                               // 1: the optimised poses sit in the second pose buffer
     int error;                               // 1: a barrier timed out, 2: aborted by the host (speculative solve no longer needed)
-    int pad0, pad1;
+    int device_ticks;                        // the leader's wall clock from its first to its last instruction, 100 MHz ticks
+    int pad1;
 };
 
 struct PersistArgs {
@@ -1018,6 +1019,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
             o.chi2_total = currentChi;
             o.x_sel = n_commit & 1;
             o.error = !alive ? 1 : (aborted ? 2 : 0);
+            o.device_ticks = (int)(prof_now() - tk0);
             *P.out = o;
             prof_add(P.prof, kProfTotal, tk0);
         }
@@ -1111,11 +1113,13 @@ public:
         out.max_chi2 = h_out_->max_chi2; out.chi2_total = h_out_->chi2_total; out.chi2_initial = h_out_->chi2_initial;
         out.iterations = h_out_->iterations; out.tries = h_out_->tries; out.flags = h_out_->flags; out.evals = h_out_->evals;
         x_sel_ = h_out_->x_sel;
+        device_us_ = 0.01 * h_out_->device_ticks;
         aborted_ = h_out_->error == 2;
         timed_out_ = h_out_->error == 1;
         return hipSuccess;
     }
     bool aborted() const { return aborted_; }
+    double device_us() const { return device_us_; }           // of the last fetched solve (IPC_SPEC_STATS)
     // a grid barrier gave up (some workgroup of the launch never became resident beside foreign work on the GPU): the
     // result is void and the caller redoes the solve with the host-driven kernels, which need no co-residency
     bool timed_out() const { return timed_out_; }
@@ -1134,6 +1138,7 @@ private:
     hipStream_t st_ = nullptr;
     int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
     bool aborted_ = false, timed_out_ = false;
+    double device_us_ = 0.0;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
     int* d_int_ = nullptr;
     static constexpr int kTabSlots = 8;

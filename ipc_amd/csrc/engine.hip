@@ -683,6 +683,7 @@ struct ipc_engine {
     double gate_release_ms = 0.0;                      // a predicted accept still running after this long counts as a reject (0: 2.5 x the mean accepted solve)
     int helper_limit = 39;
     double st_acc_s = 0, st_rej_s = 0; long st_acc_it = 0, st_rej_it = 0, st_acc_n = 0, st_rej_n = 0;   // IPC_SPEC_STATS
+    double st_acc_dev_s = 0, st_rej_dev_s = 0;         // the same solves by the leader's own clock
     unsigned long long commit_count = 0;
     hipEvent_t ev_commit = nullptr;
     int* h_abort = nullptr;                            // host-mapped: one word per slot, the launch id to give up
@@ -994,11 +995,13 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
                         "\"host_s_tentative\": %.3f, "
                         "\"accept_solves\": %ld, \"accept_us_per_iteration\": %.1f, \"accept_ms_per_solve\": %.2f, "
                         "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f, "
+                        "\"accept_ms_per_solve_on_the_device\": %.2f, \"reject_ms_per_solve_on_the_device\": %.2f, "
                         "\"empty_slot_share\": {\"behind_an_expected_accept\": %.3f, \"no_candidate_within_the_look_ahead\": %.3f, \"cu_budget\": %.3f, \"cluster_too_large\": %.3f}}}\n",
                 h->spec_window, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
                 h->spec_t_total, h->spec_t_launch, h->spec_t_tent,
                 h->st_acc_n, 1e6 * h->st_acc_s / std::max(1L, h->st_acc_it), 1e3 * h->st_acc_s / std::max(1L, h->st_acc_n),
                 h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n),
+                1e3 * h->st_acc_dev_s / std::max(1L, h->st_acc_n), 1e3 * h->st_rej_dev_s / std::max(1L, h->st_rej_n),
                 (double)h->idle_why[0] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[1] / std::max(1ull, h->idle_why[4]),
                 (double)h->idle_why[2] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[3] / std::max(1ull, h->idle_why[4]));
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
@@ -2320,8 +2323,9 @@ static int spec_pump(ipc_engine* h)
         R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
         {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - sl.t_launch).count();
-            if (R.agree) { h->st_acc_s += dt; h->st_acc_it += o.iterations; ++h->st_acc_n; }
-            else { h->st_rej_s += dt; h->st_rej_it += o.iterations; ++h->st_rej_n; }
+            const double dev = 1e-6 * (h->dim == 3 ? sl.s3->device_us() : sl.s2->device_us());
+            if (R.agree) { h->st_acc_s += dt; h->st_acc_dev_s += dev; h->st_acc_it += o.iterations; ++h->st_acc_n; }
+            else { h->st_rej_s += dt; h->st_rej_dev_s += dev; h->st_rej_it += o.iterations; ++h->st_rej_n; }
         }
         fin_pos[nfin] = p; fin_slot[nfin] = q; ++nfin;
     }
