@@ -668,7 +668,8 @@ struct ipc_engine {
     int spec_head = -1;                                // next position to hand out; -1: pipeline empty
     int spec_window = 4, spec_ahead = 256;             // solves in flight / positions ahead of the head (IPC_SPEC_AHEAD)
     bool window_forced = false;                        // IPC_SPEC_WINDOW given: taken as is, no probe
-    int stream_concurrency = 0;                        // streams of the window measured to run side by side (diagnostic)
+    int stream_concurrency = 0;                        // streams of the window measured to run side by side
+    int spec_active = 0;                               // slots the pipeline uses (fewer than the window when the streams share hardware queues)
     double accept_rate = 0.5;                          // running mean over the recent verdicts: how far ahead it pays to assume "reject"
     // Predicted verdicts (scheduling only, never a decision): a solve behind a candidate that is expected to be accepted
     // and whose verdict is still out will most likely be thrown away, so at most spec_behind of them are started; in
@@ -990,14 +991,14 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         if (stt.pred_ev) hipEventDestroy(stt.pred_ev);
     }
     if (h->d_prof || getenv("IPC_SPEC_STATS"))
-        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"streams_abreast\": %d, \"persist_timeouts\": %ld, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
+        fprintf(stderr, "{\"speculation\": {\"window\": %d, \"slots_in_use\": %d, \"streams_abreast\": %d, \"persist_timeouts\": %ld, \"ahead\": %d, \"launches\": %ld, \"results_used\": %ld, \"discarded\": %ld, "
                         "\"tentative_states\": %ld, \"promoted\": %ld, \"host_s_in_checks\": %.3f, \"host_s_launching\": %.3f, "
                         "\"host_s_tentative\": %.3f, "
                         "\"accept_solves\": %ld, \"accept_us_per_iteration\": %.1f, \"accept_ms_per_solve\": %.2f, "
                         "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f, "
                         "\"accept_ms_per_solve_on_the_device\": %.2f, \"reject_ms_per_solve_on_the_device\": %.2f, "
                         "\"empty_slot_share\": {\"behind_an_expected_accept\": %.3f, \"no_candidate_within_the_look_ahead\": %.3f, \"cu_budget\": %.3f, \"cluster_too_large\": %.3f}}}\n",
-                h->spec_window, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
+                h->spec_window, h->spec_active, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
                 h->spec_t_total, h->spec_t_launch, h->spec_t_tent,
                 h->st_acc_n, 1e6 * h->st_acc_s / std::max(1L, h->st_acc_it), 1e3 * h->st_acc_s / std::max(1L, h->st_acc_n),
                 h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n),
@@ -1998,6 +1999,7 @@ static int spec_ensure(ipc_engine* h)
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_abort), h->h_abort, 0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_commit, hipEventDisableTiming));
     h->slots.resize(h->spec_window);
+    h->spec_active = h->spec_window;
     if (h->max_helpers >= 0) h->helper_limit = std::min(h->helper_limit, h->max_helpers);
     // (workspaces for clusters of up to 256 loops up front, 9 MB (SE2) / 37 MB (SE3) per slot: growing them later means
     // hipFree, which waits for every solve in flight -- 0.36 s of a 2.3 s C2 run when the slots started at 48 loops)
@@ -2023,6 +2025,10 @@ static int spec_ensure(ipc_engine* h)
         // LOSES (C2: 6 abreast measured, 588 candidates/s capped at 6 against 827 with all 10 in flight -- a solve queued
         // behind another on its hardware queue still starts the moment that one ends, without a host round trip)
         h->stream_concurrency = probe_stream_concurrency(sts, n);
+        // ... except when the streams evidently share a handful of hardware queues (GPU_MAX_HW_QUEUES reached the environment
+        // after HIP had initialised: the runtime's default is 4): an expected accept -- the serial chain -- then sits behind a
+        // 13 ms reject on its queue.  C2 / C1 with 4 queues: 338 /s / 0.875 s with 16 slots, 398 /s / 0.700 s with 4.
+        if (h->stream_concurrency * 2 <= n) h->spec_active = std::max(2, h->stream_concurrency);
     }
     return IPC_OK;
 }
@@ -2296,7 +2302,7 @@ static void spec_insert_position(ipc_engine* h, int k)
 // tip, start solves on the free slots.
 static int spec_pump(ipc_engine* h)
 {
-    const int B = (int)h->slots.size();
+    const int B = std::min((int)h->slots.size(), h->spec_active > 0 ? h->spec_active : (int)h->slots.size());
     int fin_pos[64], fin_slot[64], nfin = 0;
     for (int q = 0; q < B; ++q) {
         ipc_engine::SpecSlot& sl = h->slots[q];

@@ -303,6 +303,32 @@ def test_run_after_reset_starts_from_the_open_loop_poses_every_time():
     e.close()
 
 
+def test_pipeline_falls_back_when_the_streams_share_hardware_queues():
+    """A caller that initialises HIP before GPU_MAX_HW_QUEUES is in the environment gets the runtime's 4 hardware queues; 16
+    solves on 16 streams would then queue behind each other (an expected accept behind a 13 ms reject).  The engine's probe
+    sees it and uses as many slots as run side by side; the verdicts are those of every other run."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IPC_SPEC_STATS="1")
+    env.pop("IPC_SPEC_WINDOW", None)
+    late = subprocess.run([sys.executable, os.path.join(root, "tools", "late_env_run.py"), "C1"], env=env, capture_output=True,
+                          text=True, timeout=600)
+    assert late.returncode == 0, late.stderr[-2000:]
+    m = re.search(r'"slots_in_use": (\d+), "streams_abreast": (\d+)', late.stderr)
+    assert m, late.stderr[-2000:]
+    assert int(m.group(1)) <= 8 and int(m.group(1)) == max(2, int(m.group(2))), m.group(0)
+    env2 = dict(env, GPU_MAX_HW_QUEUES="24")
+    ref = subprocess.run([sys.executable, os.path.join(root, "tools", "lib_incremental.py"), os.path.join(root, "ipc_amd", "libipc_amd.so"),
+                          "C1", "1"], env=env2, capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    m2 = re.search(r'"slots_in_use": (\d+)', ref.stderr)
+    assert m2 and int(m2.group(1)) >= 10, ref.stderr[-2000:]
+    dig = lambda out: re.search(r"digest ([0-9a-f]{16})", out).group(1)
+    assert dig(late.stdout) == dig(ref.stdout)
+
+
 def test_pipeline_is_left_mid_run_for_other_entry_points():
     """A caller that stops asking after a few candidates leaves solves in flight and results parked; the final map, the
     matrix mode and a second run must not care (they share the GPU's CUs with nothing of the pipeline)."""
