@@ -360,15 +360,18 @@ __global__ __launch_bounds__(256) void k_assemble(int N, int words, const int* s
     }
 }
 
-// Greedy set-max: candidates in processing order, 16 per round (one wave each).  Candidates whose own cell failed
-// can never join, so the order list is first compacted to those with a set diagonal bit (order preserved).
+// Greedy set-max: candidates in processing order, 32 per round (two per wave: the rows of both are requested together,
+// a round is a memory round trip).  Candidates whose own cell failed can never join, so the order list is first
+// compacted to those with a set diagonal bit (order preserved).  Within a round the candidates are taken in order: one
+// joins if its row covers the set as it stood before the round AND every member of the round taken before it.
 __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* order,
                                                   const unsigned long long* bits, unsigned char* accepted, int* live)
 {
+    constexpr int CPW = 2, RC = 16 * CPW;           // candidates per wave / per round
     extern __shared__ unsigned long long acc[];     // [words] accepted mask
-    __shared__ int okflag[16];
-    __shared__ unsigned conf[16];
-    __shared__ int kk[16];
+    __shared__ int okflag[RC];
+    __shared__ unsigned conf[RC];
+    __shared__ int kk[RC];
     __shared__ int wcount[16];
     __shared__ int nlive_s;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -392,34 +395,45 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
     }
     __threadfence_block();
     const int nlive = nlive_s;
-    for (int base = 0; base < nlive; base += 16) {
-        const int pos = base + wave;
-        const int k = pos < nlive ? live[pos] : -1;
-        bool ok = k >= 0;
-        if (k >= 0) {
-            const unsigned long long* row = bits + (size_t)k * words;
-            for (int w = lane; w < words; w += 64) {
-                const unsigned long long a = acc[w];
-                if ((row[w] & a) != a) ok = false;
-            }
-            ok = (__ballot(!ok) == 0ull);
+    for (int base = 0; base < nlive; base += RC) {
+        int k[CPW];
+        bool bad[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int pos = base + c * 16 + wave;    // (slot c * 16 + wave of the round: slots are in processing order)
+            k[c] = pos < nlive ? live[pos] : -1;
+            bad[c] = false;
         }
-        if (lane == 0) { okflag[wave] = ok ? 1 : 0; kk[wave] = k; }
+        for (int w = lane; w < words; w += 64) {
+            const unsigned long long a = acc[w];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const unsigned long long r = k[c] >= 0 ? bits[(size_t)k[c] * words + w] : ~0ull;
+                bad[c] = bad[c] || (r & a) != a;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const bool ok = k[c] >= 0 && __ballot(bad[c]) == 0ull;
+            if (lane == 0) { okflag[c * 16 + wave] = ok ? 1 : 0; kk[c * 16 + wave] = k[c]; }
+        }
         __syncthreads();
-        if (k >= 0) {
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            if (k[c] < 0) continue;
             // bits of this candidate against the other members of the round
             unsigned m = 0;
-            if (lane < 16 && kk[lane] >= 0) {
+            if (lane < RC && kk[lane] >= 0) {
                 const int o = kk[lane];
-                m = (unsigned)((bits[(size_t)k * words + (o >> 6)] >> (o & 63)) & 1ull);
+                m = (unsigned)((bits[(size_t)k[c] * words + (o >> 6)] >> (o & 63)) & 1ull);
             }
             const unsigned long long bal = __ballot(m != 0);
-            if (lane == 0) conf[wave] = (unsigned)(bal & 0xffffull);
+            if (lane == 0) conf[c * 16 + wave] = (unsigned)(bal & 0xffffffffull);
         }
         __syncthreads();
         if (tid == 0) {
             unsigned taken = 0;
-            for (int w = 0; w < 16; ++w) {
+            for (int w = 0; w < RC; ++w) {
                 if (kk[w] < 0 || !okflag[w]) continue;
                 if ((conf[w] & taken) != taken) continue;
                 taken |= 1u << w;
