@@ -466,6 +466,30 @@ def test_c2_faithful_run_against_the_oracle_fixture():
     assert big >= 100
 
 
+def test_faithful_run_rates_do_not_fall_back_to_the_unscheduled_pipeline():
+    """Floors, not targets (round 4 on one MI355X: C2 1 150 - 1 200 candidates/s, C1 0.55 - 0.62 s; before the pipeline was
+    scheduled by predicted verdicts: 800 - 850 /s and 0.81 s; one solve at a time: 105 /s and 1.9 s).  Best of three."""
+    import time
+    import bench
+    from ipc_amd.consensus import IPC
+    for workload, floor in (("C2", 700.0), ("C1", 420.0)):
+        g, cfg, _ = bench.build_workload(workload)
+        eng = IPC(g, cfg, device=0)
+        order = eng.candidate_order()
+        best = 1e30
+        for _ in range(3):
+            eng.reset()
+            eng.agreementCheck(int(order[0]))
+            eng.reset()
+            t0 = time.perf_counter()
+            for k in order:
+                eng.agreementCheck(int(k))
+            best = min(best, time.perf_counter() - t0)
+        eng.close()
+        print("\n[faithful run, %s] %.3f s, %.0f candidates/s" % (workload, best, len(order) / best))
+        assert len(order) / best >= floor, (workload, best)
+
+
 @pytest.mark.parametrize("workload,tag", [("C1", "c1"), ("C2", "c2")])
 def test_candidates_on_which_matrix_mode_and_the_reference_algorithm_differ(workload, tag):
     """north_star asks for the reference's accepted set; the batched matrix + set-max is a re-formulation and does NOT
