@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <map>
 #include <mutex>
 #include <string>
 #include <chrono>
@@ -716,6 +717,23 @@ static int spec_quiesce(ipc_engine* h, bool state_changes);
 // pipelines that fill the GPU between them could each end up with half-resident kernels waiting for the other's CUs.
 static ipc_engine* g_active_pipeline = nullptr;
 static std::mutex g_pipeline_mu;                       // (engines of different host threads: ipc_run_sharded, callers with one engine per thread)
+// The pipeline's streams belong to the PROCESS, per device, not to an engine: only one pipeline runs at a time, and beyond
+// about two dozen streams the runtime runs them one after the other -- a second live engine with sixteen streams of its own
+// was enough to take C1 from 0.56 to 1.2 s (round 4: the full test suite in one process).  Created on demand, never destroyed.
+static std::map<int, std::vector<hipStream_t>> g_slot_streams;
+static hipError_t pipeline_stream(int device, int q, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lk(g_pipeline_mu);
+    std::vector<hipStream_t>& pool = g_slot_streams[device];
+    while ((int)pool.size() <= q) {
+        hipStream_t st = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        pool.push_back(st);
+    }
+    *out = pool[q];
+    return hipSuccess;
+}
 
 // Device-to-device copy the host can rely on when it returns.  (hipMemcpy of this kind goes to the NULL stream and is not
 // complete -- not even submitted, as it turned out -- when the call returns; the engine's streams are non-blocking, so a
@@ -996,7 +1014,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         if (sl.st) hipStreamSynchronize(sl.st);
         delete sl.s2; delete sl.s3;
         if (sl.done) hipEventDestroy(sl.done);
-        if (sl.st) hipStreamDestroy(sl.st);
+        // (sl.st belongs to the process: pipeline_stream)
     }
     for (auto& stt : h->spec_states) {
         if (stt.owned) hipFree(stt.d_poses);
@@ -2019,7 +2037,7 @@ static int spec_ensure(ipc_engine* h)
     // hipFree, which waits for every solve in flight -- 0.36 s of a 2.3 s C2 run when the slots started at 48 loops)
     for (int q = 0; q < h->spec_window; ++q) {
         ipc_engine::SpecSlot& sl = h->slots[q];
-        HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        HIPCHK(pipeline_stream(h->device, q, &sl.st));
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (h->dim == 3) {
             sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
@@ -2371,9 +2389,6 @@ static int spec_pump(ipc_engine* h)
         n = S.pred_n;
         return S.h_pred;
     };
-    int cur_n = 0;
-    const double* cur_pred = file_pred || !predicting ? nullptr : preds_of(h->committed_state, cur_n);
-    size_t ti = 0;
     int target = B;
     if (!predicting && h->accept_rate > 0.01) {
         const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
@@ -2385,6 +2400,12 @@ static int spec_pump(ipc_engine* h)
     // the positions to launch: lowest first, the ones from the head on that have neither a parked result nor a solve in flight
     const int end = std::min(h->N, h->spec_head + h->spec_ahead);
     int why = 1;                                       // why the scan ended (idle_why)
+    // Two scans.  The first starts nothing but the next expected accept in line, if none is running: it is the serial chain
+    // of the run, and each of the (on C2: seven) expected rejects in front of it costs 20 - 30 us of this thread to launch.
+    for (int pa_only = predicting ? 1 : 0; pa_only >= 0; --pa_only) {
+    int cur_n = 0;
+    const double* cur_pred = file_pred || !predicting ? nullptr : preds_of(h->committed_state, cur_n);
+    size_t ti = 0;
     bool gated = false;                                // a predicted accept with its verdict still out lies in front of lp
     int gate_hi = -1;                                  // its later vertex: the candidates that END there too may be asked for before it (cmpTime
                                                        // leaves their order open, src/utils.cpp:379-389), so they are not "behind" it
@@ -2409,8 +2430,10 @@ static int spec_pump(ipc_engine* h)
         if (at >= 0) {
             if (gated) behind += !tied;
             else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) { gated = true; gate_hi = h->h_hi[cand_lp]; }
+            if (pa_only && gated) break;               // (the chain is running)
             continue;
         }
+        if (pa_only && !pa) continue;
         if (q < 0 || running >= target) { why = -1; break; }
         if (gated && !tied && behind >= h->spec_behind) { why = 0; break; }
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
@@ -2426,6 +2449,8 @@ static int spec_pump(ipc_engine* h)
         if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject)) return rc;
         if (gated) behind += !tied;
         else if (pa) { gated = true; gate_hi = h->h_hi[cand_lp]; }
+        if (pa_only) break;
+    }
     }
     {
         int idle = 0;
