@@ -483,8 +483,6 @@ def main():
             n_inc = N if g.dim == 2 and args.workload in ("C1", "C2", "tiny", "T700") else 0
         if n_inc > 0:
             out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5, args.workload)
-            if args.workload == "C2":                  # (BASELINE configs[0], the reference's own CPU-runnable case: 71 % accepted, a serial chain)
-                out["incremental"]["configs0"] = faithful_run_of("C1")
     if rank == 0 and world == 1 and not args.no_set_only:
         # reported separately, never the headline: the accepted SET without the cells the set-max never reads
         # (ipc_run_set_only: diagonal cells first, then the pairs among the candidates whose own cell passed)
@@ -497,6 +495,11 @@ def main():
         t_so = (time.perf_counter() - t0) / 3
         out["set_only_mode"] = {"ms_per_run": t_so * 1e3, "solved_cells": int(n_so), "same_set_as_the_matrix": bool(np.array_equal(acc_so, acc)),
                                 "note": "not the metric: no consistency matrix comes out of this mode, only the accepted set"}
+    if rank == 0 and world == 1 and "incremental" in out and args.workload == "C2":
+        # BASELINE configs[0], the reference's own CPU-runnable case (71 % accepted: a serial chain), timed last and with the
+        # headline engine gone: every live engine holds streams, and beyond two dozen the runtime serialises them
+        eng.close()
+        out["incremental"]["configs0"] = faithful_run_of("C1")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
