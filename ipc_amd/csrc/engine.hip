@@ -2403,6 +2403,7 @@ static int spec_pump(ipc_engine* h)
     // Two scans.  The first starts nothing but the next expected accept in line, if none is running: it is the serial chain
     // of the run, and each of the (on C2: seven) expected rejects in front of it costs 20 - 30 us of this thread to launch.
     for (int pa_only = predicting ? 1 : 0; pa_only >= 0; --pa_only) {
+    why = 1;
     int cur_n = 0;
     const double* cur_pred = file_pred || !predicting ? nullptr : preds_of(h->committed_state, cur_n);
     size_t ti = 0;
