@@ -261,6 +261,16 @@ int ipc_final_optimize(ipc_engine_t* h, const uint8_t* accepted, int iterations,
  * column with a non-positive pivot. */
 int ipc_debug_dense_solve(int n, const double* system, int mode, int workgroups, double* x_out, int* info_out);
 
+/* The same for the BANDED capacitance system of large clusters (round 5: the faithful mode on BASELINE configs[3] / [4];
+ * the reference factors whatever computeIndependentSubgraph, src/consensus.cpp:124-171, grows the cluster to with g2o's
+ * sparse solver, src/utils.cpp:104-105).  system: nb + m - 1 columns of W + m doubles -- column j holds rows j .. j+W-1
+ * (band; W >= 64) and then the m dense rows (the wide loops' unknowns, right-hand side last); nb band columns. */
+int ipc_debug_band_solve(int nb, int m, int W, const double* system, int workgroups, double* x_out, int* info_out);
+/* The band structure found for a set of loops (host code, no GPU): a / b = first / last vertex per loop, d = 3 (SE2) or
+ * 6 (SE3) unknowns per loop, min_n = smallest system that is banded at all (0: always).  use_out 0: dense solver. */
+int ipc_debug_band_plan(int d, int nl, const int* a, const int* b, int min_n, int* use_out, int* nlb_out, int* bwb_out,
+                        int* order_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -729,6 +729,8 @@ struct PersistSe2 {
     __device__ static void b(const Dev& D, int i, double (&v)[1]) { gk_b_at(D, i, v); }
     __device__ static void bHb_psi(const Dev& D, int i, double (&v)[1]) { gk_bHb_psi_at(D, i, v); }
     __device__ static void assemble(const Dev& D, int l1, int l2) { gk_assemble_at(D, l1, l2); }
+    template <class Put, class PutRhs>
+    __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk_assemble_core(D, l1, l2, put, put_rhs); }
     __device__ static void nu(const Dev& D, int l) { gk_nu_at(D, l); }
     __device__ static void events(const Dev& D, int j) { gk_events_at(D, j); }
     __device__ static void rho(const Dev& D, int i) { gk_rho_at(D, i); }
@@ -777,6 +779,8 @@ struct PersistSe3 {
     __device__ static void b(const Dev& D, int i, double (&v)[1]) { gk3_b_at(D, i, v); }
     __device__ static void bHb_psi(const Dev& D, int i, double (&v)[1]) { gk3_bHb_psi_at(D, i, v); }
     __device__ static void assemble(const Dev& D, int l1, int l2) { gk3_assemble_at(D, l1, l2); }
+    template <class Put, class PutRhs>
+    __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk3_assemble_core(D, l1, l2, put, put_rhs); }
     __device__ static void nu(const Dev& D, int l) { gk3_nu_at(D, l); }
     __device__ static void events(const Dev& D, int j) { gk3_events_at(D, j); }
     __device__ static void rho(const Dev& D, int i) { gk3_rho_at(D, i); }
@@ -1026,6 +1030,10 @@ __global__ __launch_bounds__(kPT, 1) void cluster_persist_kernel(typename T::Dev
     }
 }
 
+}  // namespace ipc
+#include "cluster_band.hpp"     // the same solve for clusters of thousands of loops (banded capacitance system, every workgroup in every phase)
+namespace ipc {
+
 // ---- host side ----------------------------------------------------------------------------------------------
 // One solver instance = one set of workspaces + one pinned result record; launch() enqueues a solve on a stream and
 // returns, wait() blocks for its record.  Several instances on different streams run concurrently (speculative
@@ -1039,15 +1047,40 @@ public:
     const int* d_abort_word = nullptr;          // optional host-mapped word (device address); the solve stops once it is >= launch_id
     int launch_id = 0;
     int max_helpers = 39;                       // workgroups besides the leader (kLdsTotal = 141 824 bytes of LDS each: one per CU)
+    // clusters of at least this many capacitance unknowns whose loops form a band go to cluster_band_kernel
+    // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it: the dense kernel, bit for bit as in rounds 3-4.
+    int band_min_n = 2048;
 
+    PersistSolver()
+    {
+        if (const char* e = getenv("IPC_BAND_MIN_N")) { if (*e) band_min_n = atoi(e); }
+    }
     ~PersistSolver() { release(); }
+    bool last_was_band() const { return last_band_; }
+    const BandLayout& last_band_layout() const { return band_; }
 
     hipError_t launch(hipStream_t st, const double* chain, int estride, const double* cand, int cstride, const double* src,
                       int src_ld, int lo, int hi, const std::vector<int>& members, const int* from, const int* to,
                       int iterations)
     {
         const int L = hi - lo, nl = (int)members.size(), n = T::kD * nl;
-        IPC_CL_CHK(ensure(L, nl));
+        // the band structure of the cluster's loops, if it is large enough to look for one
+        BandPlan plan;
+        if (band_min_n >= 0 && n >= band_min_n) {
+            std::vector<int> a(nl), b(nl);
+            for (int l = 0; l < nl; ++l) { a[l] = std::min(from[members[l]], to[members[l]]); b[l] = std::max(from[members[l]], to[members[l]]); }
+            plan = band_plan(T::kD, a, b, band_min_n);
+        }
+        last_band_ = plan.use;
+        std::vector<int> reordered;
+        if (plan.use) {
+            reordered.resize(nl);
+            for (int q = 0; q < nl; ++q) reordered[q] = members[plan.order[q]];
+            band_.nb = T::kD * plan.nlb; band_.m = T::kD * (nl - plan.nlb) + 1; band_.W = T::kD * (plan.bwb + 1);
+            band_.ldb = band_.W + band_.m; band_.n = n;
+        }
+        const std::vector<int>& mem = plan.use ? reordered : members;
+        IPC_CL_CHK(ensure(L, nl, plan.use ? 2 * band_.doubles() : 2 * ((size_t)n + 1) * n));
         const int ld = L + 2;
         Dev& D = dev_;
         D.chain = chain; D.estride = estride; D.lo = lo; D.L = L; D.nl = nl; D.ld = ld;
@@ -1055,7 +1088,7 @@ public:
         T::carve(D, d_edge_, d_loop_, ld, nl);
         D.S = d_S_; D.ldS = n + 1;
         D.partial = nullptr; D.scal = nullptr;
-        tab_.build(lo, hi, members, from, to);
+        tab_.build(lo, hi, mem, from, to);
         // (the staging buffer of this launch must outlive its copy: launches are enqueued without waiting for the
         // previous one of this instance -- speculative solves get aborted and replaced -- so the buffers rotate)
         tab_slot_ = (tab_slot_ + 1) % kTabSlots;
@@ -1090,10 +1123,28 @@ public:
                 resident_limit = per_cu * prop.multiProcessorCount;
         });
         IPC_CL_CHK(attr_rc);
-        G = std::max(1, std::min(G, resident_limit));
         Dev D1 = D;
         T::exchange(D1);
-        hipLaunchKernelGGL(cluster_persist_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P);
+        if (plan.use) {
+            static std::once_flag band_once;
+            static hipError_t band_rc = hipSuccess;
+            std::call_once(band_once, [] {
+                band_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&cluster_band_kernel<T>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kLdsTotal));
+            });
+            IPC_CL_CHK(band_rc);
+            // workgroups: one per two tiles of a block column's trailing update ((W + m) / 64 tile rows), and enough of
+            // them that a chain phase is a handful of poses per thread
+            const int R = band_.W + band_.m, nti = (R + 63) / 64, tiles = nti * (nti + 1) / 2;
+            const int want = std::max((tiles + kPSG - 1) / kPSG, std::min(24, (L + nl) / (4 * kPT)));
+            G = 1 + std::min(max_helpers, want);
+            G = std::max(1, std::min(G, resident_limit));
+            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_};
+            hipLaunchKernelGGL(cluster_band_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P, Q);
+        } else {
+            G = std::max(1, std::min(G, resident_limit));
+            hipLaunchKernelGGL(cluster_persist_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P);
+        }
         IPC_CL_CHK(hipGetLastError());
         IPC_CL_CHK(hipMemcpyAsync(h_out_, d_out_, sizeof(PersistOut), hipMemcpyDeviceToHost, st));
         st_ = st;
@@ -1125,7 +1176,7 @@ public:
     bool timed_out() const { return timed_out_; }
 
     // workspaces for chains up to L poses and nl loops, up front
-    hipError_t reserve(int L, int nl) { return ensure(L, nl); }
+    hipError_t reserve(int L, int nl) { return ensure(L, nl, 2 * ((size_t)T::kD * nl + 1) * ((size_t)T::kD * nl)); }
     const Dev& dev() const { return dev_; }
     bool result_in_second() const { return x_sel_ != 0; }
     // problems the leader's LDS staging cannot hold go to the host-driven solver
@@ -1137,9 +1188,13 @@ private:
     Dev dev_{};
     hipStream_t st_ = nullptr;
     int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
-    bool aborted_ = false, timed_out_ = false;
+    size_t capS_ = 0;                           // doubles of d_S_ (system + factor: dense 2 (n + 1) n, banded 2 n (W + m))
+    bool aborted_ = false, timed_out_ = false, last_band_ = false;
+    BandLayout band_{};
     double device_us_ = 0.0;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
+    double *d_gpart_ = nullptr, *d_gscan_ = nullptr;       // reduction partials / scan run totals of the band kernel
+    int* d_abort_seen_ = nullptr;
     int* d_int_ = nullptr;
     static constexpr int kTabSlots = 8;
     int* h_tab_[kTabSlots] = {};
@@ -1153,6 +1208,8 @@ private:
     void release()
     {
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_); hipFree(d_ctl_); hipFree(d_out_);
+        hipFree(d_gpart_); hipFree(d_gscan_); hipFree(d_abort_seen_);
+        d_gpart_ = d_gscan_ = nullptr; d_abort_seen_ = nullptr; capS_ = 0;
         if (st_) hipStreamSynchronize(st_);
         if (h_out_) hipHostFree(h_out_);
         for (int k = 0; k < kTabSlots; ++k) {
@@ -1163,12 +1220,14 @@ private:
         d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr; d_ctl_ = nullptr; d_out_ = h_out_ = nullptr;
         capL_ = capNl_ = 0;
     }
-    hipError_t ensure(int L, int nl)
+    hipError_t ensure(int L, int nl, size_t sdoubles)
     {
         if (!h_out_) {
             IPC_CL_CHK(hipHostMalloc(&h_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_ctl_, sizeof(PersistCtl)));
+            IPC_CL_CHK(hipMalloc(&d_abort_seen_, sizeof(int) * 4));
+            IPC_CL_CHK(hipMemset(d_abort_seen_, 0, sizeof(int) * 4));
             for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipEventCreateWithFlags(&ev_tab_[k], hipEventDisableTiming));
         }
         if (L > capL_ || nl > capNl_) {
@@ -1177,18 +1236,26 @@ private:
             const int nL = L > capL_ ? std::max(L, capL_ + capL_ / 2) : capL_;
             const int nN = nl > capNl_ ? std::max(std::max(nl, 48), capNl_ + capNl_ / 2) : capNl_;
             if (st_) IPC_CL_CHK(hipStreamSynchronize(st_));        // (a launch in flight still uses the old workspaces)
-            hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_dinv_); hipFree(d_int_);
+            hipFree(d_edge_); hipFree(d_loop_); hipFree(d_dinv_); hipFree(d_int_); hipFree(d_gpart_); hipFree(d_gscan_);
             for (int k = 0; k < kTabSlots; ++k) { if (h_tab_[k]) hipHostFree(h_tab_[k]); h_tab_[k] = nullptr; tab_used_[k] = false; }
-            d_edge_ = d_loop_ = d_S_ = d_dinv_ = nullptr; d_int_ = nullptr;
+            d_edge_ = d_loop_ = d_dinv_ = d_gpart_ = d_gscan_ = nullptr; d_int_ = nullptr;
             capL_ = capNl_ = 0;
             const size_t ld = (size_t)nL + 2, n = (size_t)T::kD * nN;
             IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (T::kEdgeDoubles * ld + ld + nN)));
             IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (T::kLoopDoubles * (size_t)nN + 8)));
-            IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * 2 * (n + 1) * n));
             IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (n + kCB)));
             IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
+            IPC_CL_CHK(hipMalloc(&d_gpart_, sizeof(double) * 8 * ((ld + nN + 255) / 256 + 2)));
+            IPC_CL_CHK(hipMalloc(&d_gscan_, sizeof(double) * 27 * ((ld + 1023) / 1024 + 2)));
             for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipHostMalloc(&h_tab_[k], sizeof(int) * LoopTables::capacity(nL, nN)));
             capL_ = nL; capNl_ = nN;
+        }
+        if (sdoubles > capS_) {
+            const size_t want = std::max(sdoubles, capS_ + capS_ / 2);
+            if (st_) IPC_CL_CHK(hipStreamSynchronize(st_));
+            hipFree(d_S_); d_S_ = nullptr; capS_ = 0;
+            IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * want));
+            capS_ = want;
         }
         return hipSuccess;
     }

@@ -240,11 +240,13 @@ __global__ void gk_bHb_psi(ClusterDev D)
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
-// capacitance system: S (lower triangle, column major) and rhs
-__device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int l2)     // row block l1, column block l2
+// capacitance system: S (lower triangle) and rhs.  put(row, col, value) stores one entry of the lower triangle,
+// put_rhs(col, value) one entry of the right-hand-side row: the dense column-major array (gk_assemble_at) or the banded
+// layout of cluster_band.hpp.
+template <class Put, class PutRhs>
+__device__ __forceinline__ void gk_assemble_core(const ClusterDev& D, int l1, int l2, Put put, PutRhs put_rhs)     // row block l1, column block l2
 {
     if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
-    const int NS = 3 * D.nl;
     const int lo1 = min(gptr(D.lfrom)[l1], gptr(D.lto)[l1]), hi1 = max(gptr(D.lfrom)[l1], gptr(D.lto)[l1]);
     const int lo2 = min(gptr(D.lfrom)[l2], gptr(D.lto)[l2]), hi2 = max(gptr(D.lfrom)[l2], gptr(D.lto)[l2]);
     const int a = max(lo1, lo2), bq = min(hi1, hi2);
@@ -272,7 +274,7 @@ __device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int 
         for (int c = 0; c < 3; ++c) {
             double t = GM[r][0] * G2[c][0] + GM[r][1] * G2[c][1] + GM[r][2] * G2[c][2];
             if (l1 == l2) t += Sg[r][c];
-            st_shared(&D.S[(size_t)(3 * l2 + c) * D.ldS + (3 * l1 + r)], t);
+            put(3 * l1 + r, 3 * l2 + c, t);
         }
     if (l1 == l2) {
         const double W0 = gptr(D.ps)[6 * D.ld + hi1] - gptr(D.ps)[6 * D.ld + lo1];
@@ -280,8 +282,14 @@ __device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int 
         const double W2 = gptr(D.ps)[8 * D.ld + hi1] - gptr(D.ps)[8 * D.ld + lo1];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            st_shared(&D.S[(size_t)(3 * l1 + r) * D.ldS + NS], gptr(D.le)[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2));
+            put_rhs(3 * l1 + r, gptr(D.le)[r * D.nl + l1] - (G1[r][0] * W0 + G1[r][1] * W1 + G1[r][2] * W2));
     }
+}
+__device__ __forceinline__ void gk_assemble_at(const ClusterDev& D, int l1, int l2)
+{
+    const int NS = 3 * D.nl;
+    gk_assemble_core(D, l1, l2, [&](int row, int col, double v) { st_shared(&D.S[(size_t)col * D.ldS + row], v); },
+                     [&](int col, double v) { st_shared(&D.S[(size_t)col * D.ldS + NS], v); });
 }
 __global__ void gk_assemble(ClusterDev D)
 {

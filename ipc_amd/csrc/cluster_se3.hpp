@@ -300,11 +300,11 @@ __global__ void gk3_bHb_psi(ClusterDev3 D)
     gk_block_reduce_store<1>(v, D.partial + blockIdx.x * 4);
 }
 
-// capacitance system: S (lower triangle of 6x6 blocks, column major) and rhs
-__device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, int l2)     // row block l1, column block l2
+// capacitance system: S (lower triangle of 6x6 blocks) and rhs; put / put_rhs as in gk_assemble_core (cluster_se2.hpp)
+template <class Put, class PutRhs>
+__device__ __forceinline__ void gk3_assemble_core(const ClusterDev3& D, int l1, int l2, Put put, PutRhs put_rhs)     // row block l1, column block l2
 {
     if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
-    const int NS = 6 * D.nl;
     const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
     const int lo2 = min(D.lfrom[l2], D.lto[l2]), hi2 = max(D.lfrom[l2], D.lto[l2]);
     const int a = max(lo1, lo2), bq = min(hi1, hi2);
@@ -331,16 +331,22 @@ __device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, in
 #pragma unroll
             for (int q = 0; q < 6; ++q) acc += T[q] * D.gam[(size_t)(6 * c + q) * D.nl + l2];
             if (l1 == l2) acc += sgl[sym6_idx(r, c)];
-            st_shared(&D.S[(size_t)(6 * l2 + c) * D.ldS + (6 * l1 + r)], acc);
+            put(6 * l1 + r, 6 * l2 + c, acc);
         }
         if (l1 == l2) {
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 acc += g1[q] * (D.ps[(size_t)(21 + q) * D.ld + hi1] - D.ps[(size_t)(21 + q) * D.ld + lo1]);
-            st_shared(&D.S[(size_t)(6 * l1 + r) * D.ldS + NS], D.le[(size_t)r * D.nl + l1] - acc);
+            put_rhs(6 * l1 + r, D.le[(size_t)r * D.nl + l1] - acc);
         }
     }
+}
+__device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, int l2)
+{
+    const int NS = 6 * D.nl;
+    gk3_assemble_core(D, l1, l2, [&](int row, int col, double v) { st_shared(&D.S[(size_t)col * D.ldS + row], v); },
+                      [&](int col, double v) { st_shared(&D.S[(size_t)col * D.ldS + NS], v); });
 }
 __global__ void gk3_assemble(ClusterDev3 D)
 {

@@ -624,6 +624,7 @@ struct ipc_engine {
     int last_literal_cells = 0;
     long lm_fallbacks = 0;
     long persist_timeouts = 0;                         // persistent launches whose grid barrier gave up: redone by the host-driven solver
+    bool cns_dups = false;                             // some edge sits in the consensus set more than once (an accepted re-check, src/consensus.cpp:70)
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
@@ -717,6 +718,12 @@ static int spec_quiesce(ipc_engine* h, bool state_changes);
 // pipelines that fill the GPU between them could each end up with half-resident kernels waiting for the other's CUs.
 static ipc_engine* g_active_pipeline = nullptr;
 static std::mutex g_pipeline_mu;                       // (engines of different host threads: ipc_run_sharded, callers with one engine per thread)
+// Held for the WHOLE of every call that reads or edits an engine's pipeline state (slots, parked results, tentative
+// states, head): a check on engine A stops the pipeline of engine B (spec_reset of a FOREIGN engine), which B's owner
+// thread may be pumping at that moment -- round 4 only guarded the pointer.  Recursive: a check that falls back to the
+// host-driven solver quiesces its own pipeline from inside.  Two threads that each run a faithful loop therefore take
+// turns check by check (they would undo each other's look-ahead anyway: one pipeline per process).
+static std::recursive_mutex g_pipeline_run_mu;
 // The pipeline's streams belong to the PROCESS, per device, not to an engine: only one pipeline runs at a time, and beyond
 // about two dozen streams the runtime runs them one after the other -- a second live engine with sixteen streams of its own
 // was enough to take C1 from 0.56 to 1.2 s (round 4: the full test suite in one process).  Created on demand, never destroyed.
@@ -985,6 +992,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
 {
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
+    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);       // (no other thread's check may be resetting this engine's pipeline)
     spec_quiesce(h, true);
     {
         std::lock_guard<std::mutex> lk(g_pipeline_mu);
@@ -1071,7 +1079,7 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     free_candidates(h);
     h->last_cells = 0;
     h->ev_valid = false;
-    h->cns.clear();
+    h->cns.clear(); h->cns_dups = false;
     if (h->d_cur && h->d_open)
         HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V));
     const int ms = h->dim == 2 ? 3 : 7, is = h->dim == 2 ? 6 : 21;
@@ -1171,7 +1179,10 @@ extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const doubl
     h->ev_valid = false;
     if (h->d_slot) { h->retired.push_back(h->d_slot); h->d_slot = nullptr; }
     h->slot_world = 0;
-    spec_insert_position(h, k);
+    {
+        std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
+        spec_insert_position(h, k);
+    }
     if (index_out) *index_out = k;
     return IPC_OK;
 }
@@ -1936,7 +1947,7 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
     if (int rc = ensure_incremental(h, "ipc_incremental_reset")) return rc;
     if (int rc = spec_quiesce(h, true)) return rc;
     HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * (h->dim == 2 ? 5 : 12) * (size_t)h->V));
-    h->cns.clear();
+    h->cns.clear(); h->cns_dups = false;
     std::fill(h->handed.begin(), h->handed.end(), 0);
     h->porder = h->order;
     for (int q = 0; q < h->N; ++q) h->ppos[h->porder[q]] = q;
@@ -1954,6 +1965,41 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>
     c.lo = h->h_lo[k]; c.hi = h->h_hi[k];
     std::vector<char> inc(cns.size(), 0);
     bool found = true;
+    if (cns.size() >= 512) {
+        // Large sets (round 5: thousands of accepted loops).  The fixed point below is the connected component of k in
+        // the graph "intervals that overlap with positive length" (an edge overlaps the hull of a connected set iff it
+        // overlaps one of its members), and its re-scans cost one pass per step the hull grows: found here by one sweep over
+        // the intervals sorted by first vertex.  Same member SET; their order is by first vertex instead of by discovery
+        // (sets this large go to the banded solver, which orders its loops itself).
+        const size_t n = cns.size();
+        std::vector<int> idx(n + 1);
+        for (size_t q = 0; q <= n; ++q) idx[q] = (int)q;                   // (n = the candidate)
+        auto lo_of = [&](int q) { return q == (int)n ? h->h_lo[k] : h->h_lo[cns[q]]; };
+        auto hi_of = [&](int q) { return q == (int)n ? h->h_hi[k] : h->h_hi[cns[q]]; };
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return lo_of(x) != lo_of(y) ? lo_of(x) < lo_of(y) : x < y; });
+        size_t start = 0, pos_k = 0;
+        int reach = hi_of(idx[0]);
+        bool has_k = idx[0] == (int)n;
+        size_t cs = 0, ce = n + 1;
+        for (size_t p = 1; p <= n + 1; ++p) {
+            if (p == n + 1 || lo_of(idx[p]) >= reach) {                     // component [start, p) ends
+                if (has_k) { cs = start; ce = p; break; }
+                if (p == n + 1) break;
+                start = p; reach = hi_of(idx[p]); has_k = idx[p] == (int)n;
+            } else {
+                reach = std::max(reach, hi_of(idx[p]));
+                has_k = has_k || idx[p] == (int)n;
+            }
+        }
+        (void)pos_k;
+        for (size_t p = cs; p < ce; ++p) {
+            if (idx[p] == (int)n) continue;
+            const int e = cns[idx[p]];
+            c.lo = std::min(c.lo, h->h_lo[e]); c.hi = std::max(c.hi, h->h_hi[e]);
+            c.members.push_back(e);
+        }
+        found = false;
+    }
     while (found) {
         found = false;
         for (size_t q = 0; q < cns.size(); ++q) {
@@ -1965,11 +2011,18 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>
             c.members.push_back(e);
         }
     }
+    if (h->cns_dups) {                         // (an edge accepted twice sits in the set twice, :70, and enters the std::set once)
+        std::vector<int> uniq;
+        for (int e : c.members) if (std::find(uniq.begin(), uniq.end(), e) == uniq.end()) uniq.push_back(e);
+        c.members.swap(uniq);
+    }
     const bool intersection = !c.members.empty();                             // :50-52
     c.th = intersection ? h->prm.slow_reject_th : h->prm.fast_reject_th;
     c.iters = intersection ? h->prm.slow_reject_iter_base : h->prm.fast_reject_iter_base;
     c.nclu = (int)c.members.size();
-    c.members.push_back(k);                                                   // :56
+    // :56 -- eset_independent is a std::set of edge pointers (:47-56): a candidate that is already in the consensus set (a
+    // re-check) was absorbed above and is not inserted a second time
+    if (std::find(c.members.begin(), c.members.end(), k) == c.members.end()) c.members.push_back(k);
     if ((c.hi - c.lo) + (int)c.members.size() > 100) c.iters *= 5;            // consensus_utils.cpp:12-13
     return c;
 }
@@ -1994,6 +2047,7 @@ static int apply_accept(ipc_engine* h, hipStream_t st, double* dst, const double
 static int commit_accept(ipc_engine* h, hipStream_t st, int k, int lo, int hi, const PoseArr* X2, const double* X3, int ld3)
 {
     if (int rc = apply_accept(h, st, h->d_cur, h->d_cur, lo, hi, X2, X3, ld3)) return rc;
+    if (std::find(h->cns.begin(), h->cns.end(), k) != h->cns.end()) h->cns_dups = true;
     h->cns.push_back(k);
     return IPC_OK;
 }
@@ -2245,6 +2299,7 @@ static int spec_make_tentative(ipc_engine* h, int p, int q)
     T.has_ready = true;
     if (int rc = spec_predict_state(h, t, sl.st)) return rc;
     T.cns = P.cns;
+    if (std::find(T.cns.begin(), T.cns.end(), h->porder[p]) != T.cns.end()) h->cns_dups = true;
     T.cns.push_back(h->porder[p]);
     T.pos = p;
     h->tent.push_back(t);
@@ -2478,6 +2533,7 @@ static int spec_reset(ipc_engine* h)
 
 static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
 {
+    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
     if (int rc = spec_ensure(h)) return rc;
     {
         std::lock_guard<std::mutex> lk(g_pipeline_mu);
@@ -2575,6 +2631,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
 // the poses / the set are about to be read or edited from outside the pipeline: nothing in flight may outlive that
 static int spec_quiesce(ipc_engine* h, bool state_changes)
 {
+    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
     if (h->slots.empty()) return IPC_OK;
     if (state_changes) return spec_reset(h);
     if (h->commit_count) HIPCHK(hipEventSynchronize(h->ev_commit));
@@ -2773,6 +2830,55 @@ extern "C" int ipc_debug_dense_solve(int n, const double* system, int mode, int 
     HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);
+    return IPC_OK;
+}
+
+// The banded factorisation of the large-cluster kernel (cluster_band.hpp) on its own: `system` is the lower triangle in
+// the banded layout (column j: the W band rows j .. j+W-1, then the m dense rows; nb band columns, m - 1 dense columns),
+// the right-hand side in the last dense row.
+extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, int workgroups, double* x_out, int* info_out)
+{
+    if (nb < 0 || m < 1 || W < 64 || !system || !x_out || !info_out) return fail(IPC_ERR_ARG, "ipc_debug_band_solve: bad argument");
+    if (workgroups < 1 || workgroups > 200) return fail(IPC_ERR_ARG, "ipc_debug_band_solve: workgroups %d", workgroups);
+    BandLayout B;
+    B.nb = nb; B.m = m; B.W = W; B.ldb = W + m; B.n = nb + m - 1;
+    if (B.n < 1) return fail(IPC_ERR_ARG, "ipc_debug_band_solve: empty system");
+    const size_t sz = B.doubles();
+    double *dA = nullptr, *dx = nullptr, *ddinv = nullptr;
+    int* dinfo = nullptr;
+    PersistCtl* dctl = nullptr;
+    HIPCHK(hipMalloc(&dA, sizeof(double) * 2 * sz));
+    HIPCHK(hipMalloc(&dx, sizeof(double) * (B.n + 64)));
+    HIPCHK(hipMalloc(&ddinv, sizeof(double) * (B.n + 64)));
+    HIPCHK(hipMalloc(&dinfo, sizeof(int)));
+    HIPCHK(hipMalloc(&dctl, sizeof(PersistCtl)));
+    HIPCHK(hipMemset(dA, 0, sizeof(double) * 2 * sz));
+    HIPCHK(hipMemcpy(dA, system, sizeof(double) * (size_t)B.n * B.ldb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
+    HIPCHK(hipMemset(dctl, 0, sizeof(PersistCtl)));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bband_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * kLdsTotal)));
+    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr};
+    hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * B.n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);
+    return IPC_OK;
+}
+
+// The band structure the large-cluster solver finds for a set of loops (host code only: no GPU needed).  a / b: first /
+// last vertex per loop.  order_out[q] = the loop at position q (band loops by first vertex, then the wide ones).
+extern "C" int ipc_debug_band_plan(int d, int nl, const int* a, const int* b, int min_n, int* use_out, int* nlb_out, int* bwb_out,
+                                   int* order_out)
+{
+    if ((d != 3 && d != 6) || nl < 0 || (nl > 0 && (!a || !b)) || !use_out || !nlb_out || !bwb_out)
+        return fail(IPC_ERR_ARG, "ipc_debug_band_plan: bad argument");
+    const BandPlan P = band_plan(d, std::vector<int>(a, a + nl), std::vector<int>(b, b + nl), min_n);
+    *use_out = P.use ? 1 : 0; *nlb_out = P.nlb; *bwb_out = P.bwb;
+    if (order_out && P.use) std::copy(P.order.begin(), P.order.end(), order_out);
     return IPC_OK;
 }
 

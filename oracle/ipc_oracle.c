@@ -937,13 +937,22 @@ int oracle_ipc_agreement_check(oracle_ipc_t *h, int k, int *info_out, double *ma
             if (inter <= 0) continue;
             lo = imin(lo, t0); hi = imax(hi, t1);
             inc[c] = 1; found = 1;
-            members[nm++] = e;
+            /* eset_independent is a std::set of edge pointers (consensus.cpp:47, :165): an edge that sits in
+             * _max_consensus_set twice (a re-checked candidate is pushed again on accept, :70) enters once */
+            int dup = 0;
+            for (int m = 0; m < nm; ++m) dup |= members[m] == e;
+            if (!dup) members[nm++] = e;
         }
     }
     int intersection = nm > 0;
     double th = intersection ? h->slow_th : h->fast_th;           /* consensus.cpp:50-52 */
     int iter_base = intersection ? h->slow_iter : h->fast_iter;
-    members[nm++] = k;                                             /* consensus.cpp:56 */
+    int ncluster = nm;
+    {
+        int dup = 0;                                               /* consensus.cpp:56: insert into the same std::set */
+        for (int m = 0; m < nm; ++m) dup |= members[m] == k;
+        if (!dup) members[nm++] = k;
+    }
     int *lid = (int *)malloc(sizeof(int) * 2 * (size_t)nm);
     double *lm = (double *)malloc(sizeof(double) * (size_t)nm * ms);
     double *li = (double *)malloc(sizeof(double) * (size_t)nm * is);
@@ -968,7 +977,7 @@ int oracle_ipc_agreement_check(oracle_ipc_t *h, int k, int *info_out, double *ma
             oracle_pose_mul(dim, h->poses + (size_t)(i - 1) * ps, Z, h->poses + (size_t)i * ps);
         }
     }                                                              /* else restore: poses untouched */
-    if (info_out) { info_out[0] = lo; info_out[1] = hi; info_out[2] = nm - 1; info_out[3] = st.iterations; }
+    if (info_out) { info_out[0] = lo; info_out[1] = hi; info_out[2] = ncluster; info_out[3] = st.iterations; }
     if (maxchi2_out) *maxchi2_out = mx;
     free(inc); free(members); free(lid); free(lm); free(li); free(newposes);
     return agree;

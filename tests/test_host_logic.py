@@ -89,3 +89,87 @@ def test_oracle_matches_committed_expected(oracle, name, clean, spoiled, kw):
 def test_all_golden_files_are_listed():
     spoiled = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "*_spoiled_*.g2o")))
     assert spoiled == sorted(c[2] for c in CASES)
+
+
+# ---- round 5: the band structure the large-cluster solver finds (host code of ipc_amd/csrc/cluster_band.hpp) ---------
+def _band_plan(d, a, b, min_n):
+    import ctypes as C
+    from ipc_amd import capi
+    lib = capi.load()
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    use, nlb, bwb = C.c_int(), C.c_int(), C.c_int()
+    order = np.full(len(a), -1, dtype=np.int32)
+    capi.check(lib.ipc_debug_band_plan(d, len(a), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), min_n,
+                                       C.byref(use), C.byref(nlb), C.byref(bwb), order.ctypes.data_as(C.c_void_p)))
+    return bool(use.value), nlb.value, bwb.value, order
+
+
+def _check_plan(a, b, nlb, bwb, order):
+    """Every pair of loops whose vertex ranges overlap with positive length (reference src/consensus.cpp:157-159) lies
+    inside the band or has a wide loop in it; the band loops are ordered by first vertex."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert sorted(order.tolist()) == list(range(len(a)))
+    band = order[:nlb]
+    assert np.all(np.diff(a[band]) >= 0)
+    ov = (np.minimum(b[band][:, None], b[band][None, :]) - np.maximum(a[band][:, None], a[band][None, :])) > 0
+    p, q = np.nonzero(ov)
+    assert np.abs(p - q).max() <= bwb
+
+
+def test_band_plan_sphere_like_cluster_puts_the_outlier_candidate_in_the_border():
+    a = list(range(2000)) + [100]
+    b = [i + 50 for i in range(2000)] + [1900]
+    use, nlb, bwb, order = _band_plan(6, a, b, 2048)
+    assert use and nlb == 2000 and bwb == 49 and order[-1] == 2000
+    _check_plan(a, b, nlb, bwb, order)
+
+
+def test_band_plan_random_bounded_spans():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 20000, 3000)
+    b = a + rng.integers(2, 201, 3000)
+    # three wide loops among them, and an unsorted input
+    a[[5, 700, 2999]] = [10, 5000, 300]
+    b[[5, 700, 2999]] = [15000, 19000, 9000]
+    use, nlb, bwb, order = _band_plan(6, a, b, 2048)
+    assert use and 2980 <= nlb <= 2997 and {5, 700, 2999} <= set(order[nlb:].tolist())
+    _check_plan(a, b, nlb, bwb, order)
+    assert bwb < 80
+
+
+def test_band_plan_declines_small_and_unbanded_systems():
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 1000, 500)
+    b = a + rng.integers(2, 1000, 500)               # spans as long as the trajectory: nothing to gain
+    assert not _band_plan(3, a, b, 1024)[0]
+    assert not _band_plan(6, [0, 10], [20, 30], 2048)[0]
+    use, nlb, bwb, order = _band_plan(3, a, b, 0)    # forced (tests): still a valid structure
+    assert use
+    _check_plan(a, b, nlb, bwb, order)
+
+
+def test_oracle_counts_a_rechecked_edge_once():
+    """IPC::agreementCheck on an edge that is already in the consensus set: eset_independent is a std::set of edge pointers
+    (reference src/consensus.cpp:47-56), so the edge enters the sub-problem once although _max_consensus_set may hold it
+    twice (:70) -- its chi2 at the second check equals the first check's result state (no doubled information)."""
+    from ipc_amd import synth
+    from oracle import oracle as O
+    g = synth.small_se2()
+    inc = O.IncrementalIPC(2, g.odom_meas, g.odom_info, 10.0, 6.251, 50, 11.345, 100, g.loop_ids, g.loop_meas, g.loop_info)
+    order = O.candidate_order(g.loop_ids)
+    first = None
+    for k in order:
+        ok, info = inc.agreement_check(int(k))
+        if ok and first is None:
+            first = (int(k), info)
+    assert first is not None
+    k, info1 = first
+    n_before = len(inc.consensus())
+    ok2, info2 = inc.agreement_check(k)
+    assert ok2
+    assert info2["cluster"] >= 1                      # the edge itself was found in the set
+    assert len(inc.consensus()) == n_before + 1      # pushed again, as the reference does
+    ok3, info3 = inc.agreement_check(k)               # now twice in the set: still one copy in the sub-problem
+    assert ok3 and info3["cluster"] == info2["cluster"]
+    assert abs(info3["max_chi2"] - info2["max_chi2"]) <= 1e-6 * max(1.0, info2["max_chi2"])
