@@ -62,19 +62,22 @@ struct BandArgs {
     double* A;               // the system, B.doubles()
     double* Lf;              // the factor, same layout
     double* dinv;            // [n] reciprocal pivots
-    double* gpart;           // [runs of 256][4 waves][2] reduction partials
+    double* gpart;           // [2][runs of 256][4 waves][2] reduction partials (two buffers, see band_reduce)
     double* gscan;           // [27][runs of 1024] run totals of the prefix sums
     int nlb;                 // band loops 0 .. nlb-1 (sorted by first vertex), wide loops nlb .. nl-1
     int bwb;                 // block half-bandwidth of the band loops
     int* abort_seen;         // device word: workgroup 0 publishes what it read from the host's abort word
+    int dbg;                 // IPC_BAND_DBG (experiments): 1 = every thread fences both sides of every barrier, 2 = chain phases on workgroup 0 only
 };
 
 // ---- grid-wide phase helpers --------------------------------------------------------------------------------------
 // Every workgroup arrives once.  fence: the phase in front of the barrier wrote data with plain stores that other
 // workgroups read behind it (release before the arrival, acquire after the last one has arrived; one lane each).
+__shared__ int band_dbg_flags;
 __device__ __forceinline__ bool band_barrier(GridBar& gb, bool fence)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fence && (band_dbg_flags & 1)) __threadfence();
     __syncthreads();
     if (gb.G == 1) return true;
     gb.target += (unsigned)gb.G;
@@ -94,6 +97,7 @@ __device__ __forceinline__ bool band_barrier(GridBar& gb, bool fence)
         if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (fence && (band_dbg_flags & 1)) __threadfence();
     return __hip_atomic_load(gb.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
@@ -101,19 +105,25 @@ __device__ __forceinline__ bool band_barrier(GridBar& gb, bool fence)
 template <class F>
 __device__ __forceinline__ void band_for(int n, int G, F f)
 {
+    if ((int)blockIdx.x >= G) return;                          // (G: the workgroups that share the chain phases)
     for (int i = blockIdx.x * kPT + threadIdx.x; i < n; i += G * kPT) f(i);
 }
 
 // Sum of K per-index values over the indices 0 .. nblk*256-1; tot is the same bit pattern on every thread of every
 // workgroup and does not depend on G: wave totals of each run of 256 (DPP scan), ((w0 + w1) + w2) + w3 per run, the runs
 // in ascending order.  Ends the phase: contains its grid barrier (fenced: the phase's other outputs are published too).
+// gpart0 holds TWO buffers of 8 doubles per run: consecutive reductions alternate between them (parity), because a fast
+// workgroup starts writing the partials of the next reduction while a slow one still reads those of this one -- the
+// barrier of the reduction in between is what separates two uses of the same buffer.
 template <int K, class F>
-__device__ __forceinline__ bool band_reduce(int nblk, double* lds, double* gpart, GridBar& gb, double (&tot)[K], F f)
+__device__ __forceinline__ bool band_reduce(int nblk, double* lds, double* gpart0, unsigned& parity, GridBar& gb, int Gc, double (&tot)[K], F f)
 {
     static_assert(K <= 2, "gpart holds two values per wave");
-    const int tid = threadIdx.x, q = tid >> 8, t = tid & 255, G = gb.G;
+    double* gpart = gpart0 + (size_t)(parity & 1u) * 8 * (size_t)nblk;
+    ++parity;
+    const int tid = threadIdx.x, q = tid >> 8, t = tid & 255, G = Gc;
     double* rtot = lds + kLdsRed;                              // [nblk][K] run totals
-    for (int vb0 = (int)blockIdx.x * kPSG; vb0 < nblk; vb0 += G * kPSG) {
+    for (int vb0 = (int)blockIdx.x < G ? (int)blockIdx.x * kPSG : nblk; vb0 < nblk; vb0 += G * kPSG) {
         const int vb = vb0 + q;
         double v[K];
 #pragma unroll
@@ -153,14 +163,14 @@ __device__ __forceinline__ bool band_reduce(int nblk, double* lds, double* gpart
 // run totals go to memory, and after a barrier every run adds the sum of the totals in front of it (in run order).
 // Independent of G.  Ends with a fenced barrier.
 template <int K>
-__device__ __forceinline__ bool band_scan_k(double* arr, int L, int ld, double* lds, double* gscan, GridBar& gb)
+__device__ __forceinline__ bool band_scan_k(double* arr, int L, int ld, double* lds, double* gscan, GridBar& gb, int Gc)
 {
     constexpr int NP = (1024 + kPT - 1) / kPT;
     double* wsum = lds + kLdsWsum;                             // [K][32]
     double* carry = lds + kLdsMisc + 8;                        // [K] (K <= 27; kLdsMisc + 64 is reserved)
-    const int tid = threadIdx.x, G = gb.G;
+    const int tid = threadIdx.x, G = Gc;
     const int nruns = (L + 1023) / 1024;
-    for (int r = blockIdx.x; r < nruns; r += G) {
+    for (int r = (int)blockIdx.x < G ? (int)blockIdx.x : nruns; r < nruns; r += G) {
         const int base = 1 + 1024 * r;
         double v[NP][K];
 #pragma unroll
@@ -201,7 +211,7 @@ __device__ __forceinline__ bool band_scan_k(double* arr, int L, int ld, double* 
     }
     if (nruns > 1) {
         if (!band_barrier(gb, false)) return false;            // (only the run totals cross workgroups here: sc1 stores / loads)
-        for (int r = blockIdx.x; r < nruns; r += G) {
+        for (int r = (int)blockIdx.x < G ? (int)blockIdx.x : nruns; r < nruns; r += G) {
             if (r == 0) continue;
             if (tid < K) {
                 double c = 0.0;
@@ -223,12 +233,12 @@ __device__ __forceinline__ bool band_scan_k(double* arr, int L, int ld, double* 
     }
     return band_barrier(gb, true);
 }
-__device__ __forceinline__ bool band_scan(double* arr, int K, int L, int ld, double* lds, double* gscan, GridBar& gb)
+__device__ __forceinline__ bool band_scan(double* arr, int K, int L, int ld, double* lds, double* gscan, GridBar& gb, int Gc)
 {
     bool alive = true;
-    while (K >= 9 && alive) { alive = band_scan_k<9>(arr, L, ld, lds, gscan, gb); arr += 9 * (size_t)ld; K -= 9; }
-    while (K >= 3 && alive) { alive = band_scan_k<3>(arr, L, ld, lds, gscan, gb); arr += 3 * (size_t)ld; K -= 3; }
-    while (K >= 1 && alive) { alive = band_scan_k<1>(arr, L, ld, lds, gscan, gb); arr += (size_t)ld; K -= 1; }
+    while (K >= 9 && alive) { alive = band_scan_k<9>(arr, L, ld, lds, gscan, gb, Gc); arr += 9 * (size_t)ld; K -= 9; }
+    while (K >= 3 && alive) { alive = band_scan_k<3>(arr, L, ld, lds, gscan, gb, Gc); arr += 3 * (size_t)ld; K -= 3; }
+    while (K >= 1 && alive) { alive = band_scan_k<1>(arr, L, ld, lds, gscan, gb, Gc); arr += (size_t)ld; K -= 1; }
     return alive;
 }
 
@@ -342,6 +352,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
     }
     alive = band_barrier(gb, false);
     for (int k0 = 0; k0 < n && alive; k0 += kCB) {
+        const unsigned long long tw0 = prof_now();
         const int nbk = min(kCB, n - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         constexpr int kDtPass = kCB * kCB / kPT;
@@ -450,7 +461,11 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
             publish(k1, nb2);
             dn_to_dt(nb2);
         }
+        prof_add(gb.prof, kProfFactorWork, tw0);
+        const unsigned long long tb0 = prof_now();
         alive = band_barrier(gb, false);
+        prof_add(gb.prof, kProfFactorWait, tb0);
+        if (gb.prof && threadIdx.x == 0 && blockIdx.x == 0) gb.prof[kProfSteps] += 1;
     }
     return info;
 }
@@ -557,6 +572,8 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
 __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* x, PersistCtl* ctl, int* info)
 {
     extern __shared__ double lds[];
+    if (threadIdx.x == 0) band_dbg_flags = 0;
+    __syncthreads();
     GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error, nullptr};
     bool alive = true;
     const int r = bband_factor(Q.A, Q.Lf, Q.dinv, Q.B, gb, lds, alive);
@@ -574,7 +591,9 @@ __device__ __forceinline__ void band_assemble_block(const typename T::Dev& Dv, c
 {
     double* A = Q.A;
     const BandLayout B = Q.B;
-    T::assemble_core(Dv, l1, l2, [&](int row, int col, double v) { st_shared(&A[B.at(row, col)], v); },
+    // (a diagonal block comes as a full d x d block; the banded layout holds the lower triangle only -- an entry above
+    // the diagonal would land in the previous column's dense rows)
+    T::assemble_core(Dv, l1, l2, [&](int row, int col, double v) { if (row >= col) st_shared(&A[B.at(row, col)], v); },
                      [&](int col, double v) { st_shared(&A[B.at(B.n, col)], v); });
 }
 
@@ -593,6 +612,9 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     (void)D0; (void)D1;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+    if (tid == 0) band_dbg_flags = Q.dbg;
+    __syncthreads();
+    const int Gc = (Q.dbg & 2) ? 1 : G;                       // workgroups that share the chain phases
     GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error, P.prof};
     const int L = D0.L, nl = D0.nl, ld = D0.ld;
     constexpr int d = T::kD;
@@ -602,14 +624,15 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     const unsigned long long tk0 = prof_now();
     const int nidx = L + nl + 1, nblk = (nidx + 255) / 256;
     int n_commit = 0;
+    unsigned red_parity = 0;
 
-    { const Dev Dv = view(0); band_for(L + 1, G, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
+    { const Dev Dv = view(0); band_for(L + 1, Gc, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
     alive = band_barrier(gb, true);
 
     auto evaluate = [&](bool trial) {
         double tot[1];
         const Dev Dv = view(vsel);
-        alive = band_reduce<1>(nblk, lds, Q.gpart, gb, tot, [&](int i, double (&v)[1]) { T::eval(Dv, trial, i, v); }) && alive;
+        alive = band_reduce<1>(nblk, lds, Q.gpart, red_parity, gb, Gc, tot, [&](int i, double (&v)[1]) { T::eval(Dv, trial, i, v); }) && alive;
         return tot[0];
     };
     auto assemble = [&](const Dev& Dv) {
@@ -617,28 +640,30 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         // no block covers (a column's last kD - 1 - c band rows, and the padding up to W) are zero and stay zero
         const int nlb = Q.nlb, bw1 = Q.bwb + 1;
         const long nband = (long)nlb * bw1, nwide = (long)(nl - nlb) * nl;
-        for (long q = (long)g * kPT + tid; q < nband + nwide; q += (long)G * kPT) {
+        const int Ga = (Q.dbg & 4) ? 1 : G;
+        if (g >= Ga) return;
+        for (long q = (long)g * kPT + tid; q < nband + nwide; q += (long)Ga * kPT) {
             int l1, l2;
             if (q < nband) { l1 = (int)(q / bw1); l2 = l1 - (int)(q - (long)l1 * bw1); }
             else { const long w = q - nband; l1 = nlb + (int)(w / nl); l2 = (int)(w - (long)(l1 - nlb) * nl); }
             if (l2 >= 0 && l2 <= l1) band_assemble_block<T>(Dv, Q, l1, l2);
         }
         const int covered = d * bw1;
-        for (int j = g * kPT + tid; j < B.nb; j += G * kPT) {
+        for (int j = g * kPT + tid; j < B.nb; j += Ga * kPT) {
             const int c = j % d;
             for (int o = covered - c; o < B.W; ++o) st_shared(&Q.A[(size_t)j * B.ldb + o], 0.0);
         }
     };
     auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
         unsigned long long t0 = prof_now();
-        { const Dev Dv = view(vsel); band_for(nidx, G, [&](int i) { T::force(Dv, i); }); }
+        { const Dev Dv = view(vsel); band_for(nidx, Gc, [&](int i) { T::force(Dv, i); }); }
         alive = band_barrier(gb, true) && alive;
-        { const Dev Dv = view(vsel); double tot[1]; alive = band_reduce<1>(nblk, lds, Q.gpart, gb, tot, [&](int i, double (&v)[1]) { T::b(Dv, i, v); }) && alive; bb = tot[0]; }
-        { const Dev Dv = view(vsel); double tot[1]; alive = band_reduce<1>(nblk, lds, Q.gpart, gb, tot, [&](int i, double (&v)[1]) { T::bHb_psi(Dv, i, v); }) && alive; bHb = tot[0]; }
-        { const Dev Dv = view(vsel); alive = band_scan(Dv.ps, T::kNPS, L, ld, lds, Q.gscan, gb) && alive; }
+        { const Dev Dv = view(vsel); double tot[1]; alive = band_reduce<1>(nblk, lds, Q.gpart, red_parity, gb, Gc, tot, [&](int i, double (&v)[1]) { T::b(Dv, i, v); }) && alive; bb = tot[0]; }
+        { const Dev Dv = view(vsel); double tot[1]; alive = band_reduce<1>(nblk, lds, Q.gpart, red_parity, gb, Gc, tot, [&](int i, double (&v)[1]) { T::bHb_psi(Dv, i, v); }) && alive; bHb = tot[0]; }
+        { const Dev Dv = view(vsel); alive = band_scan(Dv.ps, T::kNPS, L, ld, lds, Q.gscan, gb, Gc) && alive; }
         prof_add(P.prof, kProfPre, t0); t0 = prof_now();
         { const Dev Dv = view(vsel); assemble(Dv); }
-        alive = band_barrier(gb, false) && alive;
+        alive = band_barrier(gb, (Q.dbg & 8) != 0) && alive;
         prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
         if (alive) info = bband_factor(Q.A, Q.Lf, Q.dinv, B, gb, lds, alive);
@@ -651,18 +676,18 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         alive = band_barrier(gb, true) && alive;
         info = __hip_atomic_load(&P.ctl->le_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         prof_add(P.prof, kProfBacksolve, t0); t0 = prof_now();
-        { const Dev Dv = view(vsel); band_for(nl, G, [&](int l) { T::nu(Dv, l); }); }
+        { const Dev Dv = view(vsel); band_for(nl, Gc, [&](int l) { T::nu(Dv, l); }); }
         alive = band_barrier(gb, true) && alive;
-        { const Dev Dv = view(vsel); band_for(L + 2, G, [&](int j) { T::events(Dv, j); }); }
+        { const Dev Dv = view(vsel); band_for(L + 2, Gc, [&](int j) { T::events(Dv, j); }); }
         alive = band_barrier(gb, true) && alive;
-        { const Dev Dv = view(vsel); alive = band_scan(Dv.nd, T::kNND, L, ld, lds, Q.gscan, gb) && alive; }
-        { const Dev Dv = view(vsel); band_for(nidx, G, [&](int i) { T::rho(Dv, i); }); }
+        { const Dev Dv = view(vsel); alive = band_scan(Dv.nd, T::kNND, L, ld, lds, Q.gscan, gb, Gc) && alive; }
+        { const Dev Dv = view(vsel); band_for(nidx, Gc, [&](int i) { T::rho(Dv, i); }); }
         alive = band_barrier(gb, true) && alive;
-        { const Dev Dv = view(vsel); alive = band_scan(Dv.sc, T::kSC1, L, ld, lds, Q.gscan, gb) && alive; }
-        { const Dev Dv = view(vsel); band_for(nidx, G, [&](int i) { T::term(Dv, i); }); }
+        { const Dev Dv = view(vsel); alive = band_scan(Dv.sc, T::kSC1, L, ld, lds, Q.gscan, gb, Gc) && alive; }
+        { const Dev Dv = view(vsel); band_for(nidx, Gc, [&](int i) { T::term(Dv, i); }); }
         alive = band_barrier(gb, true) && alive;
-        { const Dev Dv = view(vsel); alive = band_scan(Dv.sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds, Q.gscan, gb) && alive; }
-        { const Dev Dv = view(vsel); double tot[2]; alive = band_reduce<2>(nblk, lds, Q.gpart, gb, tot, [&](int i, double (&v)[2]) { T::h(Dv, i, v); }) && alive; hh = tot[0]; bh = tot[1]; }
+        { const Dev Dv = view(vsel); alive = band_scan(Dv.sc + (size_t)T::kSC1 * ld, T::kSC2, L, ld, lds, Q.gscan, gb, Gc) && alive; }
+        { const Dev Dv = view(vsel); double tot[2]; alive = band_reduce<2>(nblk, lds, Q.gpart, red_parity, gb, Gc, tot, [&](int i, double (&v)[2]) { T::h(Dv, i, v); }) && alive; hh = tot[0]; bh = tot[1]; }
         prof_add(P.prof, kProfPost, t0);
         if (P.prof && tid == 0 && g == 0) P.prof[kProfIterations] += 1;
         return info;
@@ -714,7 +739,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
             else {
                 stepType = 2;
                 double tot[2];
-                { const Dev Dv = view(vsel); alive = band_reduce<2>(nblk, lds, Q.gpart, gb, tot, [&](int i, double (&v)[2]) { T::blend(Dv, alpha, i, v); }) && alive; }
+                { const Dev Dv = view(vsel); alive = band_reduce<2>(nblk, lds, Q.gpart, red_parity, gb, Gc, tot, [&](int i, double (&v)[2]) { T::blend(Dv, alpha, i, v); }) && alive; }
                 const double c = tot[0], bma = tot[1];
                 const double hsdSq = alpha * alpha * bb;
                 if (c <= 0.) beta = (-c + sqrt(c * c + bma * (delta * delta - hsdSq))) / bma;
@@ -728,7 +753,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
             const double bhdl = pcoef * bb + qcoef * bh;
             double linearGain = -1 * hdlHhdl + 2 * bhdl;
             double changed[1];
-            { const Dev Dv = view(vsel); alive = band_reduce<1>(nblk, lds, Q.gpart, gb, changed, [&](int i, double (&v)[1]) { T::update(Dv, pcoef, qcoef, i, v); }) && alive; }
+            { const Dev Dv = view(vsel); alive = band_reduce<1>(nblk, lds, Q.gpart, red_parity, gb, Gc, changed, [&](int i, double (&v)[1]) { T::update(Dv, pcoef, qcoef, i, v); }) && alive; }
             const bool anyChanged = changed[0] != 0.0;
             const double newChi = evaluate(true);
             if (!alive) break;
@@ -763,7 +788,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     }
     }
     // per-edge chi2 of the committed state, their maximum on workgroup 0
-    { const Dev Dv = view(vsel); band_for(nidx, G, [&](int i) { T::chi_edges(Dv, i); }); }
+    { const Dev Dv = view(vsel); band_for(nidx, Gc, [&](int i) { T::chi_edges(Dv, i); }); }
     if (alive) alive = band_barrier(gb, true);
     if (g != 0) return;
     {

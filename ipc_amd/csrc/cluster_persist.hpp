@@ -1139,7 +1139,10 @@ public:
             const int want = std::max((tiles + kPSG - 1) / kPSG, std::min(24, (L + nl) / (4 * kPT)));
             G = 1 + std::min(max_helpers, want);
             G = std::max(1, std::min(G, resident_limit));
-            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_};
+            if (getenv("IPC_BAND_DEBUG"))
+                fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d\n", L, nl, plan.nlb, plan.bwb,
+                        n, band_.W, band_.m, G);
+            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, getenv("IPC_BAND_DBG") ? atoi(getenv("IPC_BAND_DBG")) : 0};
             hipLaunchKernelGGL(cluster_band_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P, Q);
         } else {
             G = std::max(1, std::min(G, resident_limit));
@@ -1245,7 +1248,7 @@ private:
             IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (T::kLoopDoubles * (size_t)nN + 8)));
             IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (n + kCB)));
             IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
-            IPC_CL_CHK(hipMalloc(&d_gpart_, sizeof(double) * 8 * ((ld + nN + 255) / 256 + 2)));
+            IPC_CL_CHK(hipMalloc(&d_gpart_, sizeof(double) * 2 * 8 * ((ld + nN + 255) / 256 + 2)));
             IPC_CL_CHK(hipMalloc(&d_gscan_, sizeof(double) * 27 * ((ld + 1023) / 1024 + 2)));
             for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipHostMalloc(&h_tab_[k], sizeof(int) * LoopTables::capacity(nL, nN)));
             capL_ = nL; capNl_ = nN;

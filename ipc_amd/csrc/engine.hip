@@ -2859,7 +2859,7 @@ extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, 
     HIPCHK(hipStreamSynchronize(nullptr));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bband_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * kLdsTotal)));
-    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr};
+    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, 0};
     hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
