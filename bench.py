@@ -161,15 +161,21 @@ def cpu_baseline(g, cfg, cells, budget_s):
     n1 = int(max(n_probe, min(len(pick), rate1 * budget_s * 0.4)))
     t1, idx1, mx1, its1, _ = run(pick[:n1], 1)
     rate1 = n1 / t1
-    # all cores: a short all-core probe gives the rate the box really delivers (shared hosts, SMT); then what ~0.6 x
-    # budget_s of wall time holds at that rate, the whole workload if that is less
+    # all cores (warm-up discarded, median of >= 5): a short all-core probe gives the rate the box really
+    # delivers (shared hosts, SMT); the sample is what ~1/8 of 0.7 x budget_s holds at that rate -- at least 64 cells per
+    # thread, the WHOLE workload if that is less (C1) -- and is run 1 + 5 times: the first run is the warm-up
     nprobe_all = int(min(len(cells), 8 * cores))
     tp = run(_stratified_sample(cells, nprobe_all, seed=2), cores)[0]
-    want = int(nprobe_all / max(tp, 1e-9) * budget_s * 0.6)
+    want = int(nprobe_all / max(tp, 1e-9) * budget_s * 0.7 / 6.0)
     whole = want >= len(cells)
     n_all = len(cells) if whole else int(min(len(cells), max(want, 64 * cores)))
     sel = np.arange(len(cells)) if whole else _stratified_sample(cells, n_all, seed=1)
-    t_all, idxa, mxa, itsa, used = run(sel, cores)
+    reps_all = []
+    for rep in range(6):
+        t_rep, idxa, mxa, itsa, used = run(sel, cores)
+        if rep > 0:
+            reps_all.append(t_rep)
+    t_all = float(np.median(reps_all))
     th_all = np.where(cells["i"] == cells["j"], cfg.fast_reject_th, cfg.slow_reject_th)
     nl = np.where(cells["i"] == cells["j"], 1, 2)
     cap_all = np.where(cells["i"] == cells["j"], cfg.fast_reject_iter_base, cfg.slow_reject_iter_base) * np.where(Lall + nl > 100, 5, 1)
@@ -181,13 +187,14 @@ def cpu_baseline(g, cfg, cells, budget_s):
     one = dict(value=rate1, unit="solved candidate-pairs/s", cores=1, kind="port",
                sample="%d solved cells (prefix of an L-stratified sample), %.1f s, one run" % (n1, t1))
     return dict(value=n_all / t_all, unit="solved candidate-pairs/s (compare with solved_cells_per_s, not with value)", cores=used, kind="port",
-                sample="%s, one shared work queue (longest chains first) over %d POSIX threads (the host shows %d logical CPUs; affinity and the cgroup CPU quota leave %d), one run "
-                       "of %.1f s; the CPU side is this repo's plain-C restatement (oracle/), not g2o -- the reference cannot "
+                sample="%s, one shared work queue (longest chains first) over %d POSIX threads (the host shows %d logical CPUs; affinity and the cgroup CPU quota leave %d), warm-up run "
+                       "discarded, median of 5 runs = %.2f s; the CPU side is this repo's plain-C restatement (oracle/), not g2o -- the reference cannot "
                        "be built here; non-overlapping pairs are free on both sides and excluded from this rate" % (
                            ("ALL %d solved cells of the workload" % n_all) if whole else
                            ("%d solved cells, L-stratified over the chain-length order of the same workload (%d per thread)"
                             % (n_all, n_all // max(used, 1))), used, os.cpu_count() or 1, cores, t_all),
                 whole_workload=bool(whole),
+                run_seconds=[round(t, 3) for t in reps_all],
                 scaling_over_1_thread=(n_all / t_all) / rate1,
                 single_thread=one,
                 decisions_differing_from_gpu=mism,
@@ -198,7 +205,7 @@ def cpu_baseline(g, cfg, cells, budget_s):
                                                   "on rounding (g2o has no convergence test), decisions agree there too"})
 
 
-def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload):
+def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload, reps=3):
     """The reference's own metric (src/simulation.cpp:36-44,87): mean wall time per agreementCheck in the faithful
     incremental mode, as candidates/s.  GPU: ipc_agreement_check over the WHOLE candidate list (device-resident
     dog-leg, speculative window).  CPU: the oracle's IncrementalIPC (1 thread) on the prefix of the processing order
@@ -209,7 +216,7 @@ def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload):
     order = eng.candidate_order()
     n_gpu = len(order) if gpu_candidates <= 0 else min(gpu_candidates, len(order))
     t_gpu, acc_gpu, stamps, runs = 1e30, None, None, []
-    for _ in range(3):                            # best of three (a run is ~1 s; single runs spread by 15 %: one host thread feeds 16 streams)
+    for _ in range(reps):                         # (a run of C1 / C2 is ~1 s and single runs spread by 15 %: one host thread feeds 16 streams)
         eng.reset()
         eng.agreementCheck(int(order[0]))        # warm-up: workspaces, streams
         eng.reset()
@@ -238,7 +245,9 @@ def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload):
             break
     t_cpu = time.perf_counter() - t0
     n_cpu = len(acc_cpu)
-    out = dict(unit="candidates/s", gpu=n_gpu / t_gpu, gpu_candidates=n_gpu, gpu_avg_time_x_test_s=t_gpu / n_gpu,
+    med = float(np.median(runs))
+    out = dict(unit="candidates/s", gpu=med, gpu_is="median of %d run%s" % (len(runs), "" if len(runs) == 1 else "s"), gpu_best_run=n_gpu / t_gpu,
+               gpu_candidates=n_gpu, gpu_avg_time_x_test_s=1.0 / med, gpu_seconds_per_run=[round(n_gpu / r, 3) for r in runs],
                gpu_accepted=int(sum(acc_gpu)), gpu_runs=[round(r, 1) for r in runs],
                cpu_1t_prefix=n_cpu / t_cpu, cpu_prefix_candidates=n_cpu, cpu_avg_time_x_test_s_prefix=t_cpu / n_cpu,
                gpu_on_the_same_prefix=n_cpu / stamps[n_cpu - 1],
@@ -248,10 +257,16 @@ def incremental_metric(g, cfg, eng, gpu_candidates, cpu_budget_s, workload):
     fx = os.path.join(ROOT, "tests", "golden", "%s_incremental_expected.npz" % workload.lower())
     if os.path.exists(fx) and n_gpu == len(order):
         exp = np.load(fx)
-        if np.array_equal(exp["order"], order):
-            out["decisions_differing_from_the_oracle_full_run"] = int((exp["decision"].astype(bool) != np.array(acc_gpu)).sum())
-            out["oracle_full_run_s_authoring_container_1_thread"] = float(exp["oracle_seconds_authoring_container"])
-            out["oracle_full_run_source"] = os.path.relpath(fx, ROOT)
+        ne = len(exp["order"])
+        if np.array_equal(exp["order"], order[:ne]):
+            full = ne == len(order)
+            key = "oracle_full_run" if full else "oracle_prefix_run"
+            out["decisions_differing_from_the_%s" % key] = int((exp["decision"].astype(bool) != np.array(acc_gpu[:ne])).sum())
+            out["%s_s_authoring_container_1_thread" % key] = float(exp["oracle_seconds_authoring_container"])
+            out["%s_candidates" % key] = int(ne)
+            out["%s_source" % key] = os.path.relpath(fx, ROOT)
+            if not full:
+                out["gpu_seconds_on_the_oracle_prefix"] = stamps[ne - 1]
     return out
 
 
@@ -262,8 +277,8 @@ def faithful_run_of(workload):
     g, cfg, _ = build_workload(workload)
     eng = IPC(g, cfg, device=0)
     order = eng.candidate_order()
-    best, acc = 1e30, None
-    for _ in range(2):
+    times, acc = [], None
+    for _ in range(3):
         eng.reset()
         eng.agreementCheck(int(order[0]))
         eng.reset()
@@ -271,9 +286,11 @@ def faithful_run_of(workload):
         t0 = time.perf_counter()
         acc = [eng.agreementCheck(int(k)) for k in order]
         eng.synchronize()
-        best = min(best, time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
     eng.close()
-    out = dict(workload=workload, candidates=len(order), seconds=best, candidates_per_s=len(order) / best, accepted=int(sum(acc)))
+    med = float(np.median(times))
+    out = dict(workload=workload, candidates=len(order), seconds=med, seconds_is="median of 3 runs", seconds_per_run=[round(t, 3) for t in times],
+               candidates_per_s=len(order) / med, accepted=int(sum(acc)))
     fx = os.path.join(ROOT, "tests", "golden", "%s_incremental_expected.npz" % workload.lower())
     if os.path.exists(fx):
         exp = np.load(fx)
@@ -330,9 +347,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-set-only", action="store_true", help="skip the set-only side measurement (kernel traces of the matrix steps alone)")
-    ap.add_argument("--incremental-candidates", type=int, default=-1,
-                    help="candidates of the faithful incremental mode to time (reference metric); -1: all of them for "
-                         "the SE2 workloads at 1 GPU, none otherwise; 0: none")
+    ap.add_argument("--incremental-candidates", type=int, default=None,
+                    help="candidates of the faithful incremental mode to time (reference metric); -1: all of them (C4: minutes, "
+                         "C5: tens of minutes -- one run instead of three); 0: none; default: all for C1 / C2 / tiny / T700 at 1 GPU, "
+                         "none otherwise")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -417,10 +435,14 @@ def main():
     use_ex = ex is not None and ex["current"] is not False
     ach_flops = ex["flops"] if use_ex else survey_flops
     achieved_tflops = ach_flops / (sms * 1e-3) / 1e12
+    alg_tflops = survey_flops / (sms * 1e-3) / 1e12
     roofline = {"bound": "fp64-valu", "contract_bound": "mfma",
-                "achieved": round(achieved_tflops, 4), "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
-                "frac_basis": ("executed FP64 flops (%s: SQ_INSTS_VALU_{FMA x2,MUL,ADD,TRANS}_F64 x 64 lanes of one solve of "
+                "achieved": round(alg_tflops, 4), "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(alg_tflops / FP64_PEAK_TFLOPS, 5), "traffic": traffic,
+                "frac_is": "ALGORITHMIC: SURVEY.md 8(d)'s K L F_d (pose_iterations_per_step x %g flop) / kernel_ms_per_step / peak; the executed "
+                           "fraction of the counter pass is frac_executed" % F_SURVEY[g.dim],
+                "achieved_executed": round(achieved_tflops, 4),
+                "frac_executed_basis": ("executed FP64 flops (%s: SQ_INSTS_VALU_{FMA x2,MUL,ADD,TRANS}_F64 x 64 lanes of one solve of "
                                "this workload = %.4g) / kernel_ms_per_step / peak" % (ex["source"], ex["flops"])) if use_ex
                               else "SURVEY.md 8(d) model: pose_iterations_per_step x %g flop / kernel_ms_per_step / peak" % F_SURVEY[g.dim],
                 "frac_survey_model": round(survey_flops / (sms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
@@ -478,11 +500,40 @@ def main():
         out["cpu_baseline"]["gpu_solved_cells_per_s"] = gpu_solved_rate
         out["cpu_baseline"]["gpu_over_cpu_all_cores_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["value"]
         out["cpu_baseline"]["gpu_over_cpu_1_thread_on_solved_cells"] = gpu_solved_rate / out["cpu_baseline"]["single_thread"]["value"]
+        if ms_per_step < 2500.0:
+            # the same matrix by g2o's LITERAL trial loop (no convergence test: IPC_TERMINATE_EPS=0), i.e. the algorithm the
+            # CPU baseline runs, on the GPU: the ratio on identical algorithms
+            old_eps = os.environ.get("IPC_TERMINATE_EPS")
+            os.environ["IPC_TERMINATE_EPS"] = "0"
+            try:
+                eng_lit = IPC(g, cfg, device=local_rank)
+            finally:
+                if old_eps is None:
+                    del os.environ["IPC_TERMINATE_EPS"]
+                else:
+                    os.environ["IPC_TERMINATE_EPS"] = old_eps
+            sm_lit = ShardedMatrix(EngineBackend(eng_lit), 0, 1)
+            sm_lit.step()
+            torch.cuda.synchronize()
+            t0l = time.perf_counter()
+            for _ in range(2):
+                sm_lit.step()
+            torch.cuda.synchronize()
+            lit_ms = (time.perf_counter() - t0l) / 2 * 1e3
+            _, acc_lit = sm_lit.result()
+            eng_lit.close()
+            out["cpu_baseline"]["gpu_literal_loop_ms_per_step"] = lit_ms
+            out["cpu_baseline"]["gpu_literal_loop_same_accepted_set"] = bool(np.array_equal(acc_lit, acc))
+            out["cpu_baseline"]["gpu_literal_loop_over_cpu_all_cores_on_solved_cells"] = (len(cells) / (lit_ms * 1e-3)) / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["gpu_literal_loop_over_cpu_1_thread_on_solved_cells"] = (len(cells) / (lit_ms * 1e-3)) / out["cpu_baseline"]["single_thread"]["value"]
         n_inc = args.incremental_candidates
-        if n_inc < 0:
+        if n_inc is None:
             n_inc = N if g.dim == 2 and args.workload in ("C1", "C2", "tiny", "T700") else 0
+        elif n_inc < 0:
+            n_inc = N
         if n_inc > 0:
-            out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5, args.workload)
+            big = args.workload in ("C3", "C4", "C5")
+            out["incremental"] = incremental_metric(g, cfg, eng, n_inc, args.cpu_seconds * 0.5, args.workload, reps=1 if big else 3)
     if rank == 0 and world == 1 and not args.no_set_only:
         # reported separately, never the headline: the accepted SET without the cells the set-max never reads
         # (ipc_run_set_only: diagonal cells first, then the pairs among the candidates whose own cell passed)

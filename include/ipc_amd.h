@@ -21,9 +21,10 @@
  *   - a handle is bound to one GPU and must not be used from two threads at once (the
  *     reference's IPC object is not re-entrant either).
  *   - environment: the faithful mode keeps up to 16 solves in flight, one per HIP stream; streams that share a hardware
- *     queue run one after the other and the runtime's default is 4 queues.  Export GPU_MAX_HW_QUEUES=24 before the
- *     process's first HIP call for full speed (ipc_create sets it when it is unset, which only helps if ipc_create IS the
- *     first HIP call -- true for the testers; ipc_amd/capi.py exports it at import).  IPC_SPEC_STATS=1 prints how many
+ *     queue run one after the other and the runtime's default is 4 queues.  The HOST PROGRAM exports
+ *     GPU_MAX_HW_QUEUES=24 before its first HIP call for full speed (the library does not touch the environment: round 5;
+ *     ipc_tester_2D/3D and bench.py do it in their main, INTEGRATION.md shows the line for the reference's testers).
+ *     Without it the window is 4 solves and a probe measures how many streams really run abreast.  IPC_SPEC_STATS=1 prints how many
  *     of the engine's streams were measured to run side by side.  The order in which the pipeline starts its solves
  *     follows a prediction of each verdict (the candidate's own chi2 at the poses it starts from; IPC_SPEC_PREDICT,
  *     INTEGRATION.md): predictions schedule, no result depends on them.
@@ -125,12 +126,15 @@ int ipc_row_assignment(int n, const int* ids, int world, int policy, int* slot_o
  * pairs are not solved (their bit stays 0; see ipc_assemble_matrix). */
 int ipc_solve_rows(ipc_engine_t* h, int rank, int world, uint64_t* d_upper, void* stream);
 /* Stream contract of ipc_solve_rows: the call enqueues on `stream` and on streams of the engine that
- * fork from / join back into it, and it blocks the HOST twice: once before the cell kernels (the cell
- * counts come back from the planning pass; buffers grow with hipMalloc on the first call or when N
- * grows) and once behind them (the number of cells to solve again: failed factorisations, IPC_LM_RETRY,
- * and cells within IPC_BORDERLINE_BAND of their threshold -- the second wait is skipped when both are
- * off).  Whatever the faithful mode has in flight is given up first (it restarts with the next
- * ipc_agreement_check).  Cells whose chain
+ * fork from / join back into it, and it blocks the HOST ONCE: behind the cell kernels, for the counts of the
+ * cells to solve again (failed factorisations, IPC_LM_RETRY, and cells within IPC_BORDERLINE_BAND of their
+ * threshold; skipped when both are off).  The borderline cells are then solved again on the device by the cell
+ * kernels themselves (g2o's literal trial loop, compact per-bin lists built on the device, no copies through the
+ * host); only cells whose linear solve failed -- degenerate information matrices -- go one by one through the
+ * host-driven Levenberg solver.  The FIRST call after the candidates, the rank or the world changed blocks once
+ * more, before the cell kernels: the planning pass's cell counts come back and buffers grow with hipMalloc; the
+ * cell lists are then kept (round 5).  Whatever the faithful mode has in flight is given up first (it restarts with
+ * the next ipc_agreement_check).  Cells whose chain
  * is longer than the largest cell kernel (SE3: 4096 poses, SE2: 16384 with the default policies) are
  * solved one at a time by the cluster solver of ipc_agreement_check -- correct for any length, host
  * driven and slow (reference cfg/3D/GRID_params.yaml: 8000 poses); ipc_solve_report() counts them. */

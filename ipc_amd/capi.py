@@ -9,10 +9,16 @@ import os
 
 import numpy as np
 
-# The faithful incremental mode keeps up to 20 cluster solves in flight, one persistent launch per HIP stream; streams that
-# share a hardware queue run one after the other and the runtime defaults to 4 queues.  Read once, when the HIP runtime
-# initialises -- so it has to be in the environment before the first HIP call of the process (torch's included).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
+
+def export_recommended_environment():
+    """The faithful incremental mode keeps up to 16 cluster solves in flight, one persistent launch per HIP stream; streams
+    that share a hardware queue run one after the other and the runtime defaults to 4 queues.  GPU_MAX_HW_QUEUES is read
+    once, when the HIP runtime initialises -- so it has to be in the environment before the first HIP call of the process
+    (torch's included).  That is the HOST PROGRAM's decision: bench.py, the tools and tests/conftest.py call this first
+    thing; importing the binding no longer edits the environment (round 5)."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPC_AMD_LIB") or os.path.join(_HERE, "libipc_amd.so")   # (IPC_AMD_LIB: A/B builds, tools/)

@@ -67,6 +67,7 @@ struct BandArgs {
     int nlb;                 // band loops 0 .. nlb-1 (sorted by first vertex), wide loops nlb .. nl-1
     int bwb;                 // block half-bandwidth of the band loops
     int* abort_seen;         // device word: workgroup 0 publishes what it read from the host's abort word
+    const double* zero;      // a word that holds 0.0 (entries outside the profile are read from it)
     int dbg;                 // IPC_BAND_DBG (experiments): 1 = every thread fences both sides of every barrier, 2 = chain phases on workgroup 0 only
 };
 
@@ -245,8 +246,10 @@ __device__ __forceinline__ bool band_scan(double* arr, int K, int L, int ld, dou
 // ---- blocked Cholesky on the banded layout (cluster_persist.hpp::chol_tile / pchol_factor, rows by BandRows) ----------
 template <class AfterLoads>
 __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayout& B, const BandRows& TR, int k0, int nbk, bool has,
-                                           int bx, int by, const double* DT, double* panel, bool skip_next_diag, AfterLoads after_loads)
+                                           int bx, int by, const double* DT, double* panel, bool skip_next_diag, unsigned long long* prof,
+                                           AfterLoads after_loads)
 {
+    const unsigned long long ts0 = prof_now();
     const int t = threadIdx.x & 255, wv = t >> 6, lane = t & 63;
     const int k1 = k0 + nbk;
     const int i0v = bx * 64, j0v = by * 64;
@@ -265,14 +268,38 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         const bool ok = c < nbk && pvalid && B.in(prow, k0 + c);
         x[s2] = ld_shared(&A[ok ? B.at(prow, k0 + c) : (size_t)0]);
     }
+    // the tile's old values do not depend on the panel solve: requested with the panel rows (one trip to memory for
+    // both; they come from memory -- sc1 -- and a trip costs 2 - 4 us here, more than the solve and the product together)
+    const TileOwn own{wv, lane};
+    double old[16];
+    unsigned adr[16];                                          // (a system holds < 2^31 doubles)
+    unsigned inmask = 0;
+    const bool upd = has && j0v < TR.R - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int iv = i0v + own.i_of(e), jv = j0v + own.j_of(e);
+        const bool inr = upd && jv < TR.R - 1 && iv < TR.R && iv >= jv;
+        const int i = TR.row(inr ? iv : 0), j = TR.row(inr ? jv : 0);
+        bool in = inr && B.in(i, j);
+        // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
+        if (skip_next_diag && i < min(k1 + kCB, B.n)) in = false;
+        adr[e] = in ? (unsigned)B.at(i, j) : 0u;
+        inmask |= (in ? 1u : 0u) << e;
+        old[e] = ld_shared(&A[adr[e]]);
+    }
     after_loads();
+    prof_add1(prof, kProfBsDots, ts0);
+    unsigned long long tq = prof_now();
     if (has) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             const int c = s2 * LPR + q;
             x[s2] = (c < nbk && pvalid && B.in(prow, k0 + c)) ? x[s2] : 0.0;
         }
+        asm volatile("" :: "v"(x[0]), "v"(x[NS - 1]));
+        prof_add1(prof, kProfBsPrefetch, tq); tq = prof_now();
         trsm32_lanes<LPR>(x, DT, q);
+        prof_add1(prof, kProfBsSync, tq); tq = prof_now();
         double (*P)[64 + 1] = first ? Ai : Aj;
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) P[s2 * LPR + q][lrow] = (s2 * LPR + q) < nbk ? x[s2] : 0.0;
@@ -285,23 +312,10 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         }
     }
     __syncthreads();
-    if (has && j0v < TR.R - 1) {
-        const TileOwn own{wv, lane};
-        double old[16];
-        unsigned adr[16];                                      // (a system holds < 2^31 doubles)
-        unsigned inmask = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int iv = i0v + own.i_of(e), jv = j0v + own.j_of(e);
-            const bool inr = jv < TR.R - 1 && iv < TR.R && iv >= jv;
-            const int i = TR.row(inr ? iv : 0), j = TR.row(inr ? jv : 0);
-            bool in = inr && B.in(i, j);
-            // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
-            if (skip_next_diag && i < min(k1 + kCB, B.n)) in = false;
-            adr[e] = in ? (unsigned)B.at(i, j) : 0u;
-            inmask |= (in ? 1u : 0u) << e;
-            old[e] = ld_shared(&A[adr[e]]);
-        }
+    prof_add1(prof, kProfBsTri, tq);
+    prof_add1(prof, kProfHelpSolve, ts0);
+    const unsigned long long tu0 = prof_now();
+    if (upd) {
         double acc[16];
         tile_product(Ai, Aj, own, acc);
 #pragma unroll
@@ -309,6 +323,7 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
             if (inmask & (1u << e)) st_shared(&A[adr[e]], old[e] - acc[e]);
     }
     __syncthreads();
+    prof_add1(prof, kProfHelpUpdate, tu0);
 }
 
 // Factor the banded system A (B.n unknowns, right-hand side = last dense row) into Lf / dinv; all G workgroups call it
@@ -390,10 +405,10 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                 if (has) { while (rem >= nti - by) { rem -= nti - by; ++by; } }
                 if (base == 0)
                     bchol_tile(A, Lf, B, TR, k0, nbk, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
-                               G > 1 && has && by == 0 && rem == 0, write_dt);
+                               G > 1 && has && by == 0 && rem == 0, gb.prof, write_dt);
                 else
                     bchol_tile(A, Lf, B, TR, k0, nbk, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
-                               G > 1 && has && by == 0 && rem == 0, [] {});
+                               G > 1 && has && by == 0 && rem == 0, gb.prof, [] {});
             }
             if (total == 0) write_dt();
         }
@@ -410,6 +425,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                 // rows k1 .. k1+nb2 of block column k0 against the block, then the update of the next diagonal block with
                 // them: the operations bchol_tile applies, in its order (rows k1 .. k1+31 are inside the profile of every
                 // column of the block: W >= 64)
+                unsigned long long tl0 = prof_now();
                 constexpr int kTri = kCB * (kCB + 1) / 2, kTriPass = (kTri + kPT - 1) / kPT;
                 double oldv[kTriPass];
                 int er[kTriPass], es[kTriPass];
@@ -435,12 +451,14 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) x[s2] = ((s2 * LPR + q) < nbk && pvalid) ? x[s2] : 0.0;
+                    prof_add(gb.prof, kProfLookLoad, tl0); tl0 = prof_now();
                     trsm32_lanes<LPR>(x, DT, q);
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) Lrow[s2 * LPR + q][lrow] = (s2 * LPR + q) < nbk ? x[s2] : 0.0;
                 }
                 for (int idx = tid; idx < kCB * kCB; idx += kPT) Dn[idx >> 5][idx & 31] = (idx >> 5) == (idx & 31) ? 1.0 : 0.0;
                 __syncthreads();
+                prof_add(gb.prof, kProfLookSolve, tl0); tl0 = prof_now();
 #pragma unroll
                 for (int q = 0; q < kTriPass; ++q) {
                     const int idx = tid + q * kPT, r = er[q], sc = es[q];
@@ -451,20 +469,25 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                         Dn[r][sc] = oldv[q] - acc;
                     }
                 }
+                prof_add(gb.prof, kProfLookFill, tl0);
             }
             __syncthreads();
+            unsigned long long tp0 = prof_now();
             bool ok = true;
             if (tid < 64) ok = potrf32_wave(Dn, Dninv);
             if (tid == 0) lds[kLdsMisc] = ok ? 0.0 : 1.0;
             __syncthreads();
+            prof_add(gb.prof, kProfLookPotrf, tp0); tp0 = prof_now();
             if (lds[kLdsMisc] != 0.0 && info == 0) info = k1 + 1;
             publish(k1, nb2);
             dn_to_dt(nb2);
+            prof_add(gb.prof, kProfLookPub, tp0);
         }
         prof_add(gb.prof, kProfFactorWork, tw0);
         const unsigned long long tb0 = prof_now();
         alive = band_barrier(gb, false);
         prof_add(gb.prof, kProfFactorWait, tb0);
+        prof_add1(gb.prof, kProfHelpWait, tb0);
         if (gb.prof && threadIdx.x == 0 && blockIdx.x == 0) gb.prof[kProfSteps] += 1;
     }
     return info;
@@ -473,7 +496,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
 // L^T x = y (y = the last dense row of the factor), workgroup 0 only: cluster_persist.hpp::pchol_backsolve on the banded
 // layout.  Per block column (from the last): the dots with the already solved unknowns run over the rows of the column's
 // profile (BandRows without the right-hand side), their factor entries requested one block column ahead.
-__device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout B, double* x, double* lds)
+__device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout B, double* x, double* lds, const double* zero)
 {
     constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 12, DPT = (kCB * kCB + kPT - 1) / kPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
@@ -484,20 +507,30 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31;
     const int nblk = (n + kCB - 1) / kCB;
     double pre[CPW][MAXM], dpre[DPT], ypre = 0.0;
+    // entry (r, j) sits at j * (ldb - 1) + r for a band row, at j * ldb + (W - nb) + r for a dense row; entries outside
+    // the profile are read from a word that holds 0.0, so the dots below need no mask
     auto prefetch = [&](int kb) {
         const int k0 = kb * kCB, nbk = min(kCB, n - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
+        unsigned jb[CPW], jd[CPW];
+        int jc[CPW];
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            jc[q] = k0 + min(wave + q * NW, nbk - 1);             // (columns beyond a short block: a valid one, result unused)
+            jb[q] = (unsigned)jc[q] * (unsigned)(B.ldb - 1);
+            jd[q] = (unsigned)jc[q] * (unsigned)B.ldb + (unsigned)(B.W - B.nb);
+        }
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
             if (64 * m < Rm) {                                // (wave-uniform)
                 const int v = lane + 64 * m;
                 const int r = TR.row(v < Rm ? v : 0);
+                const bool dense = r >= B.nb;
 #pragma unroll
                 for (int q = 0; q < CPW; ++q) {
-                    const int c = min(wave + q * NW, nbk - 1);
-                    const bool ok = v < Rm && B.in(r, k0 + c);
-                    pre[q][m] = ld_shared(&Lf[ok ? B.at(r, k0 + c) : (size_t)0]);
+                    const bool ok = v < Rm && (dense || r - jc[q] < B.W);
+                    pre[q][m] = ld_shared(ok ? &Lf[(dense ? jd[q] : jb[q]) + (unsigned)r] : zero);
                 }
             }
         }
@@ -514,13 +547,15 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
         double xr[MAXM];
-        int rr[MAXM];
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
-            const int v = lane + 64 * m;
-            rr[m] = v < Rm ? TR.row(v) : -1;
-            const int rc = rr[m] >= 0 ? rr[m] : 0;
-            xr[m] = x_in_lds ? xs[rc] : gptr(x)[rc];
+            xr[m] = 0.0;
+            if (64 * m < Rm) {                                // (wave-uniform)
+                const int v = lane + 64 * m;
+                const int rc = v < Rm ? TR.row(v) : -1;
+                const double xv = x_in_lds ? xs[rc >= 0 ? rc : 0] : gptr(x)[rc >= 0 ? rc : 0];
+                xr[m] = rc >= 0 ? xv : 0.0;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -530,7 +565,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
                 double acc = 0.0;
 #pragma unroll
                 for (int m = 0; m < MAXM; ++m)
-                    if (rr[m] >= 0 && B.in(rr[m], k0 + c)) acc += pre[q][m] * xr[m];
+                    if (64 * m < Rm) acc += pre[q][m] * xr[m];
                 for (int v = lane + 64 * MAXM; v < Rm; v += 64) {
                     const int r = TR.row(v);
                     if (B.in(r, k0 + c)) acc += ld_shared(&Lf[B.at(r, k0 + c)]) * gptr(x)[r];
@@ -578,7 +613,7 @@ __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* 
     bool alive = true;
     const int r = bband_factor(Q.A, Q.Lf, Q.dinv, Q.B, gb, lds, alive);
     if (blockIdx.x == 0) {
-        bband_backsolve(Q.Lf, Q.B, x, lds);
+        bband_backsolve(Q.Lf, Q.B, x, lds, Q.zero);
         if (threadIdx.x == 0) *info = alive ? r : -1;
     }
 }
@@ -670,7 +705,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
         if (g == 0 && alive) {
             const Dev Dv = view(vsel);
-            bband_backsolve(Q.Lf, B, Dv.rhs, lds);
+            bband_backsolve(Q.Lf, B, Dv.rhs, lds, Q.zero);
             if (tid == 0) __hip_atomic_store(&P.ctl->le_sel, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the solver's word, for everyone)
         }
         alive = band_barrier(gb, true) && alive;

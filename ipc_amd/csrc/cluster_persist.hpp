@@ -1142,7 +1142,7 @@ public:
             if (getenv("IPC_BAND_DEBUG"))
                 fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d\n", L, nl, plan.nlb, plan.bwb,
                         n, band_.W, band_.m, G);
-            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, getenv("IPC_BAND_DBG") ? atoi(getenv("IPC_BAND_DBG")) : 0};
+            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8), getenv("IPC_BAND_DBG") ? atoi(getenv("IPC_BAND_DBG")) : 0};
             hipLaunchKernelGGL(cluster_band_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P, Q);
         } else {
             G = std::max(1, std::min(G, resident_limit));
@@ -1179,7 +1179,13 @@ public:
     bool timed_out() const { return timed_out_; }
 
     // workspaces for chains up to L poses and nl loops, up front
-    hipError_t reserve(int L, int nl) { return ensure(L, nl, 2 * ((size_t)T::kD * nl + 1) * ((size_t)T::kD * nl)); }
+    // nl: loops the per-loop arrays and tables hold (cheap: ~100 doubles per loop); nl_dense: loops the DENSE capacitance
+    // system + factor are reserved for (2 (d nl)^2 doubles; larger clusters are banded and grow the buffer as they come)
+    hipError_t reserve(int L, int nl, int nl_dense = -1)
+    {
+        if (nl_dense < 0) nl_dense = nl;
+        return ensure(L, nl, 2 * ((size_t)T::kD * nl_dense + 1) * ((size_t)T::kD * nl_dense));
+    }
     const Dev& dev() const { return dev_; }
     bool result_in_second() const { return x_sel_ != 0; }
     // problems the leader's LDS staging cannot hold go to the host-driven solver
@@ -1229,8 +1235,8 @@ private:
             IPC_CL_CHK(hipHostMalloc(&h_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_out_, sizeof(PersistOut)));
             IPC_CL_CHK(hipMalloc(&d_ctl_, sizeof(PersistCtl)));
-            IPC_CL_CHK(hipMalloc(&d_abort_seen_, sizeof(int) * 4));
-            IPC_CL_CHK(hipMemset(d_abort_seen_, 0, sizeof(int) * 4));
+            IPC_CL_CHK(hipMalloc(&d_abort_seen_, sizeof(int) * 16));       // [0]: abort word as workgroup 0 saw it; [8..9]: a double 0.0
+            IPC_CL_CHK(hipMemset(d_abort_seen_, 0, sizeof(int) * 16));
             for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipEventCreateWithFlags(&ev_tab_[k], hipEventDisableTiming));
         }
         if (L > capL_ || nl > capNl_) {
@@ -1254,7 +1260,7 @@ private:
             capL_ = nL; capNl_ = nN;
         }
         if (sdoubles > capS_) {
-            const size_t want = std::max(sdoubles, capS_ + capS_ / 2);
+            const size_t want = std::max(sdoubles + sdoubles / 4, 2 * capS_);      // (hipFree waits for the whole device: few, large steps)
             if (st_) IPC_CL_CHK(hipStreamSynchronize(st_));
             hipFree(d_S_); d_S_ = nullptr; capS_ = 0;
             IPC_CL_CHK(hipMalloc(&d_S_, sizeof(double) * want));

@@ -593,6 +593,15 @@ struct ipc_engine {
     int n_cu = 256;
     int2* d_cells = nullptr; size_t cells_cap = 0;
     double *d_chi = nullptr, *d_chitot = nullptr; int4* d_meta = nullptr;
+    // The cell lists of (rank, world) change only with the candidates: the two planning passes and their read-back (the
+    // first of ipc_solve_rows' two host waits) are paid once per candidate list, not once per step (round 5).
+    bool plan_cached = false; int plan_rank = -1, plan_world = 0; size_t plan_total = 0;
+    std::vector<unsigned> plan_counts, plan_offsets;
+    // Borderline cells (borderline_band) are solved again with g2o's literal trial loop BY THE CELL KERNELS (term_eps 0)
+    // over compact per-slot lists built on the device -- no per-cell copies, no host-driven solves (round 5).
+    int2* d_lit_cells = nullptr; int* d_lit_idx = nullptr; double *d_lit_chi = nullptr, *d_lit_chitot = nullptr; int4* d_lit_meta = nullptr;
+    unsigned* d_slot_off = nullptr;                    // [slots + 1] first cell of each (loop count, bin) slot
+    int* d_recount = nullptr; int* h_recount = nullptr;   // [slots] borderline cells per slot, then the failed-cell count; pinned copy
     int last_cells = 0, last_long_cells = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false; int last_launches = 0;
     // side streams: the bin launches of one solve are spread over them so that the tail of one
@@ -804,10 +813,10 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (n_vertices < 2 || !odom_meas || !odom_info || !params)
         return fail(IPC_ERR_ARG, "ipc_create: need >= 2 vertices and non-NULL arrays");
     if (!(params->s_factor > 0)) return fail(IPC_ERR_ARG, "ipc_create: s_factor must be > 0");
-    // The speculative window of the faithful mode runs one persistent launch per stream; streams that share a hardware
-    // queue run their kernels one after the other, and the runtime's default is 4 queues.  Only effective when this is
-    // the process's first HIP call (otherwise export GPU_MAX_HW_QUEUES before starting; ipc_amd/capi.py does).
-    setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    // (The speculative window of the faithful mode runs one persistent launch per stream; streams that share a hardware
+    // queue run their kernels one after the other, and the runtime's default is 4 queues.  The HOST PROGRAM exports
+    // GPU_MAX_HW_QUEUES=24 before its first HIP call -- the testers' main() and bench.py do; a library does not edit its
+    // process's environment (round 5).  Without it the window below is 4 and the stream probe of spec_ensure applies.)
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(IPC_ERR_ARG, "ipc_create: device %d of %d", device, ndev);
@@ -879,8 +888,11 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
         if (h->n_side > ipc_engine::kMaxSide) h->n_side = ipc_engine::kMaxSide;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join_own, hipEventDisableTiming));
+        // the side streams come from the per-device pool of the PROCESS, the one the pipeline's slots use (the pipeline is
+        // quiesced before any matrix-mode launch, matrix_mode_enter): an engine owns one stream, so how many engines are
+        // alive no longer decides whether the runtime's couple of dozen usable streams are exceeded (round 5)
         for (int k = 0; k < h->n_side; ++k) {
-            HIPCHK(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+            HIPCHK(pipeline_stream(device, k, &h->side[k]));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
         }
     }
@@ -1002,6 +1014,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
     hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
     hipFree(h->d_upper); hipFree(h->d_bits); hipFree(h->d_acc); hipFree(h->d_failed);
+    hipFree(h->d_lit_cells); hipFree(h->d_lit_idx); hipFree(h->d_lit_chi); hipFree(h->d_lit_chitot); hipFree(h->d_lit_meta);
+    hipFree(h->d_slot_off); hipFree(h->d_recount); if (h->h_recount) hipHostFree(h->h_recount);
     hipFree(h->d_chain1); if (h->d_open != h->d_pose0) hipFree(h->d_open); hipFree(h->d_cur);
     delete h->cluster;
     delete h->cluster3;
@@ -1055,7 +1069,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     if (h->ev_join_own) hipEventDestroy(h->ev_join_own);
     for (int k = 0; k < h->n_side; ++k) {
         if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
-        if (h->side[k]) hipStreamDestroy(h->side[k]);
+        // (side[k] belongs to the process's stream pool)
     }
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -1078,6 +1092,7 @@ static int upload_candidates(ipc_engine* h, int n, const int* ids, const double*
     if (int rc = spec_quiesce(h, true)) return rc;
     free_candidates(h);
     h->last_cells = 0;
+    h->plan_cached = false;
     h->ev_valid = false;
     h->cns.clear(); h->cns_dups = false;
     if (h->d_cur && h->d_open)
@@ -1176,6 +1191,7 @@ extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const doubl
     h->N = k + 1;
     h->order_stale = true;
     h->last_cells = 0;                                   // the cells of the last matrix solve are those of the shorter list
+    h->plan_cached = false;
     h->ev_valid = false;
     if (h->d_slot) { h->retired.push_back(h->d_slot); h->d_slot = nullptr; }
     h->slot_world = 0;
@@ -1376,56 +1392,59 @@ static int ensure_row_map(ipc_engine* h, int world)
 // poses): g2o retries such a solve with Levenberg damping.  The cell kernels cannot (see cluster_common.hpp), so the
 // few cells concerned are solved again by the host-driven cluster solver, which can -- same check, open-loop start.
 // Borderline cells (see ipc_engine::borderline_band) are collected by the same pass, listed as ~c.
+__device__ __forceinline__ int slot_of_cell(const unsigned* slot_off, int nslots, int c)
+{
+    int lo = 0, hi = nslots;                                 // last slot whose first cell is <= c (empty slots share an offset: take the last)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (slot_off[mid] <= (unsigned)c) lo = mid; else hi = mid; }
+    return lo;
+}
+// Failed cells -> list (host-driven Levenberg retry, rare); borderline cells -> the compact list of their slot (lit_cells /
+// lit_idx at the slot's own offset: a slot has room for all of its cells), counted per slot in recount[0 .. nslots).
 __global__ void k_collect_failed(int ncells, const int4* meta, const double* chi, const int2* cells, double fast_th,
-                                 double slow_th, double band, bool want_failed, int cap, int* list, int* count)
+                                 double slow_th, double band, bool want_failed, int cap, int* list, int* recount,
+                                 const unsigned* slot_off, int nslots, int2* lit_cells, int* lit_idx)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
     const bool failed = want_failed && (meta[c].z & 2);
     bool border = false;
+    const int2 cc = cells[c];
     if (!failed && band > 0.0) {
-        const int2 cc = cells[c];
         const double th = cc.x == cc.y ? fast_th : slow_th;
         border = fabs(chi[c] - th) <= band * th;                     // (NaN: no)
     }
-    if (!failed && !border) return;
-    const int q = atomicAdd(count, 1);
-    if (q < cap) list[q] = failed ? c : ~c;
-}
-static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
-{
-    // (the list can hold every cell: IPC_BORDERLINE_BAND up to 0.5 may select most of them, and none may be dropped silently)
-    if (total > h->failed_cap) {
-        HIPCHK(hipFree(h->d_failed));
-        h->d_failed = nullptr;
-        h->failed_cap = std::max(16384, total + total / 8);
-        HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * ((size_t)h->failed_cap + 1)));
+    if (failed) {
+        const int q = atomicAdd(recount + nslots, 1);
+        if (q < cap) list[q] = c;
+    } else if (border) {
+        const int sl = slot_of_cell(slot_off, nslots, c);
+        const int q = atomicAdd(recount + sl, 1);
+        lit_cells[slot_off[sl] + q] = cc;
+        lit_idx[slot_off[sl] + q] = c;
     }
-    const int kCap = h->failed_cap;
-    HIPCHK(hipMemsetAsync(h->d_failed + kCap, 0, sizeof(int), st));
-    const double band = h->term_eps > 0 ? (h->borderline_band >= 0 ? h->borderline_band : 4.0 * std::sqrt(h->term_eps)) : 0.0;
-    hipLaunchKernelGGL(k_collect_failed, dim3((total + 255) / 256), dim3(256), 0, st, total, (const int4*)h->d_meta,
-                       (const double*)h->d_chi, (const int2*)h->d_cells, h->prm.fast_reject_th, h->prm.slow_reject_th, band,
-                       h->lm_retry, kCap, h->d_failed, h->d_failed + kCap);
-    int n = 0;
-    HIPCHK(hipMemcpyAsync(&n, h->d_failed + kCap, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+}
+// the literal re-solves back to where their cells sit
+__global__ void k_scatter_literal(int ncells, const unsigned* slot_off, int nslots, const int* recount, const int* lit_idx,
+                                  const double* lit_chi, const double* lit_chitot, const int4* lit_meta, double* chi, double* chitot, int4* meta)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncells) return;
+    const int sl = slot_of_cell(slot_off, nslots, t);
+    if ((int)(t - slot_off[sl]) >= recount[sl]) return;
+    const int c = lit_idx[t];
+    chi[c] = lit_chi[t]; chitot[c] = lit_chitot[t]; meta[c] = lit_meta[t];
+}
+static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int n)
+{
+    (void)st;
     h->last_lm_cells = 0;
-    h->last_literal_cells = 0;
     if (n == 0) return IPC_OK;
-    n = std::min(n, kCap);
+    n = std::min(n, h->failed_cap);
     if (int rc = ensure_incremental(h, "ipc_solve_rows")) return rc;
     std::vector<int> idx(n);
     HIPCHK(hipMemcpy(idx.data(), h->d_failed, sizeof(int) * n, hipMemcpyDeviceToHost));
-    std::sort(idx.begin(), idx.end(), [](int a, int b) { return (a < 0 ? ~a : a) < (b < 0 ? ~b : b); });
-    auto set_eps = [&](double eps) {
-        if (h->dim == 3) { h->cluster3->term_eps = eps; if (h->persist3) h->persist3->term_eps = eps; }
-        else { h->cluster->term_eps = eps; if (h->persist2) h->persist2->term_eps = eps; }
-    };
+    std::sort(idx.begin(), idx.end());
     for (int q = 0; q < n; ++q) {
-        const bool literal = idx[q] < 0;                             // borderline: the same check by g2o's literal loop
-        if (literal) idx[q] = ~idx[q];
-        set_eps(literal ? 0.0 : h->term_eps);
         int2 cell;
         HIPCHK(hipMemcpy(&cell, h->d_cells + idx[q], sizeof(int2), hipMemcpyDeviceToHost));
         const int i = cell.x, j = cell.y, nl = i == j ? 1 : 2;
@@ -1435,16 +1454,14 @@ static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int total)
         int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
         if ((hi - lo) + nl > 100) iters *= 5;                                  // consensus_utils.cpp:12-13
         ClusterOut o;
-        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, !literal));    // (damping: host-driven solver)
+        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, true));    // (damping: host-driven solver)
         const int4 meta = make_int4(o.iterations, o.tries, o.flags, o.evals);
         HIPCHK(hipMemcpy(h->d_chi + idx[q], &o.max_chi2, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_chitot + idx[q], &o.chi2_total, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_meta + idx[q], &meta, sizeof(int4), hipMemcpyHostToDevice));
-        if (literal) ++h->last_literal_cells;
-        else ++h->last_lm_cells;
+        ++h->last_lm_cells;
     }
     HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
-    set_eps(h->term_eps);
     return IPC_OK;
 }
 
@@ -1472,50 +1489,95 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     const int nb = bc.n;
     constexpr int NS = 2 * (kMaxBins + 1);
     if (phase != 2) HIPCHK(hipMemsetAsync(d_upper, 0, sizeof(uint64_t) * (size_t)rpr * words, st));
-    // pass 1: count
-    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    const int nrows = h->row_group_off[rank + 1] - h->row_group_off[rank];
-    const int* rows = h->d_rowperm + h->row_group_off[rank];
-    const dim3 pgrid((N + 255) / 256, std::max(1, std::min(nrows, 2048))), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
-                       h->d_offsets, (int2*)nullptr, 0, phase, (const unsigned long long*)d_upper, words);
-    HIPCHK(hipGetLastError());
     unsigned counts[NS], offsets[NS];
-    static thread_local unsigned subcounts[NS * kPlanSub], suboffsets[NS * kPlanSub];
-    HIPCHK(hipMemcpyAsync(subcounts, h->d_counters, sizeof subcounts, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (int s = 0; s < NS; ++s) {
-        counts[s] = 0;
-        for (int q = 0; q < kPlanSub; ++q) counts[s] += subcounts[s * kPlanSub + q];
+    size_t total = 0;
+    // The cell lists of this rank (d_cells, grouped by slot = (loop count, chain-length bin)) depend on the candidates,
+    // the rank and the world only: a repeated step reuses them and skips the two planning passes with their read-back.
+    // (The set-only phases plan from the diagonal bits of the step and are never cached.)
+    const bool cached = phase == 0 && h->plan_cached && h->plan_rank == rank && h->plan_world == world;
+    if (cached) {
+        std::copy(h->plan_counts.begin(), h->plan_counts.end(), counts);
+        std::copy(h->plan_offsets.begin(), h->plan_offsets.end(), offsets);
+        total = h->plan_total;
+    } else {
+        h->plan_cached = false;
+        // pass 1: count
+        HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
+        const int nrows = h->row_group_off[rank + 1] - h->row_group_off[rank];
+        const int* rows = h->d_rowperm + h->row_group_off[rank];
+        const dim3 pgrid((N + 255) / 256, std::max(1, std::min(nrows, 2048))), pblock(256);     // few fat blocks: dispatching one block per (row, 256 candidates) cost more than the compares
+        hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
+                           h->d_offsets, (int2*)nullptr, 0, phase, (const unsigned long long*)d_upper, words);
+        HIPCHK(hipGetLastError());
+        static thread_local unsigned subcounts[NS * kPlanSub], suboffsets[NS * kPlanSub];
+        HIPCHK(hipMemcpyAsync(subcounts, h->d_counters, sizeof subcounts, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int s = 0; s < NS; ++s) {
+            counts[s] = 0;
+            for (int q = 0; q < kPlanSub; ++q) counts[s] += subcounts[s * kPlanSub + q];
+        }
+        for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
+        for (int s = 0; s < NS; ++s) {                    // a slot's sub-lists are contiguous: one cell list per slot
+            unsigned o = offsets[s];
+            for (int q = 0; q < kPlanSub; ++q) { suboffsets[s * kPlanSub + q] = o; o += subcounts[s * kPlanSub + q]; }
+        }
+        if (total > h->cells_cap) {
+            hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
+            hipFree(h->d_lit_cells); hipFree(h->d_lit_idx); hipFree(h->d_lit_chi); hipFree(h->d_lit_chitot); hipFree(h->d_lit_meta);
+            h->d_cells = h->d_lit_cells = nullptr; h->d_chi = h->d_chitot = h->d_lit_chi = h->d_lit_chitot = nullptr;
+            h->d_meta = h->d_lit_meta = nullptr; h->d_lit_idx = nullptr;
+            h->cells_cap = total + total / 8 + 1024;
+            HIPCHK(hipMalloc(&h->d_cells, sizeof(int2) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_chi, sizeof(double) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_chitot, sizeof(double) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_meta, sizeof(int4) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_cells, sizeof(int2) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_idx, sizeof(int) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_chi, sizeof(double) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_chitot, sizeof(double) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_meta, sizeof(int4) * h->cells_cap));
+        }
+        if (!h->d_slot_off) {
+            HIPCHK(hipMalloc(&h->d_slot_off, sizeof(unsigned) * (NS + 1)));
+            HIPCHK(hipMalloc(&h->d_recount, sizeof(int) * (NS + 1)));
+            HIPCHK(hipHostMalloc(&h->h_recount, sizeof(int) * (NS + 1)));
+        }
+        // pass 2: fill
+        static thread_local unsigned slot_off[NS + 1];
+        for (int s = 0; s < NS; ++s) slot_off[s] = offsets[s];
+        slot_off[NS] = (unsigned)total;
+        HIPCHK(hipMemcpyAsync(h->d_slot_off, slot_off, sizeof slot_off, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
+        hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
+                           h->d_offsets, h->d_cells, 1, phase, (const unsigned long long*)d_upper, words);
+        HIPCHK(hipGetLastError());
+        if (phase == 0) {
+            h->plan_counts.assign(counts, counts + NS);
+            h->plan_offsets.assign(offsets, offsets + NS);
+            h->plan_total = total; h->plan_rank = rank; h->plan_world = world;
+            h->plan_cached = true;
+        }
     }
     // cells whose chain is longer than the largest kernel variant of the policy go through the cluster
     // solver below (one at a time, state in HBM: no length limit) instead of failing the matrix
     const unsigned n_long = counts[nb] + counts[(kMaxBins + 1) + nb];
-    size_t total = 0;
-    for (int s = 0; s < NS; ++s) { offsets[s] = (unsigned)total; total += counts[s]; }
-    for (int s = 0; s < NS; ++s) {                    // a slot's sub-lists are contiguous: one cell list per slot
-        unsigned o = offsets[s];
-        for (int q = 0; q < kPlanSub; ++q) { suboffsets[s * kPlanSub + q] = o; o += subcounts[s * kPlanSub + q]; }
-    }
-    if (total > h->cells_cap) {
-        hipFree(h->d_cells); hipFree(h->d_chi); hipFree(h->d_chitot); hipFree(h->d_meta);
-        h->d_cells = nullptr; h->d_chi = h->d_chitot = nullptr; h->d_meta = nullptr;
-        h->cells_cap = total + total / 8 + 1024;
-        HIPCHK(hipMalloc(&h->d_cells, sizeof(int2) * h->cells_cap));
-        HIPCHK(hipMalloc(&h->d_chi, sizeof(double) * h->cells_cap));
-        HIPCHK(hipMalloc(&h->d_chitot, sizeof(double) * h->cells_cap));
-        HIPCHK(hipMalloc(&h->d_meta, sizeof(int4) * h->cells_cap));
-    }
-    // pass 2: fill
-    HIPCHK(hipMemcpyAsync(h->d_offsets, suboffsets, sizeof suboffsets, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned) * NS * kPlanSub, st));
-    hipLaunchKernelGGL(k_plan, pgrid, pblock, 0, st, N, h->d_lo, h->d_hi, rows, nrows, bc, h->d_counters,
-                       h->d_offsets, h->d_cells, 1, phase, (const unsigned long long*)d_upper, words);
-    HIPCHK(hipGetLastError());
     // solve: longest chains first
-    const Se2View P = make_view(h);
-    const Se3View P3 = make_view3(h);
+    Se2View P = make_view(h);
+    Se3View P3 = make_view3(h);
     const SolveParams sp{h->prm.fast_reject_iter_base, h->prm.slow_reject_iter_base};
+    // one slot's cells through the kernel variant of its bin
+    auto launch_slot = [&](int b, int nl, int n, const int2* cells, const CellOut& out, hipStream_t ls, unsigned* ctr) -> hipError_t {
+        int var = h->plan.variant[b];
+        if (h->plan.latency_variant[b] >= 0 && n < h->plan.latency_below[b] * h->n_cu) var = h->plan.latency_variant[b];
+        if (h->dim == 2)
+            return var >= kQuadVariantBase   ? launch_se2_quad(nl, var - kQuadVariantBase, n, ls, P, cells, sp, out, ctr, h->n_cu)
+                   : var >= kPairVariantBase ? launch_se2_pair(nl, var - kPairVariantBase, n, ls, P, cells, sp, out, ctr, h->n_cu)
+                   : var >= kWaveVariantBase ? launch_se2_wave(nl, var - kWaveVariantBase, n, ls, P, cells, sp, out, ctr, h->n_cu)
+                                             : launch_se2_block(nl, var, n, ls, P, cells, sp, out);
+        if (var >= kLdsVariantBase3) return launch_se3_lds(nl, var - kLdsVariantBase3, n, ls, P3, cells, sp, out, ctr, h->n_cu);
+        return launch_se3_block(nl, var, n, ls, P3, cells, sp, out);
+    };
     int launches = 0;
     HIPCHK(hipMemsetAsync(h->d_wave_ctr, 0, sizeof(unsigned) * NS, st));
     HIPCHK(hipEventRecord(h->ev0, st));
@@ -1535,28 +1597,9 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
             const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
-            int var = h->plan.variant[b];
-            if (h->plan.latency_variant[b] >= 0 && (int)counts[s] < h->plan.latency_below[b] * h->n_cu)
-                var = h->plan.latency_variant[b];
             const int lane_q = launches % (h->n_side + 1);
             hipStream_t ls = lane_q == 0 ? st0 : h->side[lane_q - 1];
-            hipError_t e;
-            if (h->dim == 2)
-                e = var >= kQuadVariantBase
-                        ? launch_se2_quad(nl, var - kQuadVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
-                                          h->d_wave_ctr + s, h->n_cu)
-                    : var >= kPairVariantBase
-                        ? launch_se2_pair(nl, var - kPairVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
-                                          h->d_wave_ctr + s, h->n_cu)
-                    : var >= kWaveVariantBase
-                        ? launch_se2_wave(nl, var - kWaveVariantBase, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out,
-                                          h->d_wave_ctr + s, h->n_cu)
-                        : launch_se2_block(nl, var, (int)counts[s], ls, P, h->d_cells + offsets[s], sp, out);
-            else if (var >= kLdsVariantBase3)
-                e = launch_se3_lds(nl, var - kLdsVariantBase3, (int)counts[s], ls, P3, h->d_cells + offsets[s], sp, out,
-                                   h->d_wave_ctr + s, h->n_cu);
-            else
-                e = launch_se3_block(nl, var, (int)counts[s], ls, P3, h->d_cells + offsets[s], sp, out);
+            const hipError_t e = launch_slot(b, nl, (int)counts[s], h->d_cells + offsets[s], out, ls, h->d_wave_ctr + s);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
             ++launches;
         }
@@ -1577,8 +1620,51 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     h->last_launches = launches;
     h->last_cells = (int)total;
     h->last_long_cells = (int)n_long;
-    if (total && (h->lm_retry || (h->term_eps > 0 && h->borderline_band != 0.0))) {
-        if (int rc = resolve_failed_cells(h, st, (int)total)) return rc;
+    h->last_lm_cells = h->last_literal_cells = 0;
+    const double band = h->term_eps > 0 ? (h->borderline_band >= 0 ? h->borderline_band : 4.0 * std::sqrt(h->term_eps)) : 0.0;
+    if (total && (h->lm_retry || band > 0.0)) {
+        // The cells to solve again: failed linear solves (Levenberg retry by the host-driven solver: degenerate information,
+        // rare) and borderline cells (the literal trial loop, by the cell kernels themselves over compact per-slot lists).
+        // ONE read-back of the counts -- the single host wait of a repeated step.
+        if ((int)total > h->failed_cap) {
+            HIPCHK(hipFree(h->d_failed));
+            h->d_failed = nullptr;
+            h->failed_cap = std::max(16384, (int)(total + total / 8));
+            HIPCHK(hipMalloc(&h->d_failed, sizeof(int) * ((size_t)h->failed_cap + 1)));
+        }
+        HIPCHK(hipMemsetAsync(h->d_recount, 0, sizeof(int) * (NS + 1), st));
+        hipLaunchKernelGGL(k_collect_failed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total, (const int4*)h->d_meta,
+                           (const double*)h->d_chi, (const int2*)h->d_cells, h->prm.fast_reject_th, h->prm.slow_reject_th, band,
+                           h->lm_retry, h->failed_cap, h->d_failed, h->d_recount, (const unsigned*)h->d_slot_off, NS, h->d_lit_cells, h->d_lit_idx);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->h_recount, h->d_recount, sizeof(int) * (NS + 1), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int n_lit = 0;
+        for (int s = 0; s < NS; ++s) n_lit += h->h_recount[s];
+        if (n_lit) {
+            P.term_eps = 0.0; P3.term_eps = 0.0;                   // g2o's literal loop (Se2View::term_eps)
+            HIPCHK(hipMemsetAsync(h->d_wave_ctr, 0, sizeof(unsigned) * NS, st));
+            for (int b = nb - 1; b >= 0; --b) {
+                for (int nl = 2; nl >= 1; --nl) {
+                    const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
+                    const int n = h->h_recount[s];
+                    if (!n) continue;
+                    CellOut out{h->d_lit_chi + offsets[s], h->d_lit_chitot + offsets[s], h->d_lit_meta + offsets[s]};
+                    const hipError_t e = launch_slot(b, nl, n, h->d_lit_cells + offsets[s], out, st, h->d_wave_ctr + s);
+                    if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
+                }
+            }
+            // (borderline cells beyond every cell kernel were solved by the cluster solver with the engine's term_eps; their
+            // slot is not re-solved: counts of the long slots are skipped above because b < nb)
+            hipLaunchKernelGGL(k_scatter_literal, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
+                               (const unsigned*)h->d_slot_off, NS, (const int*)h->d_recount, (const int*)h->d_lit_idx, (const double*)h->d_lit_chi,
+                               (const double*)h->d_lit_chitot, (const int4*)h->d_lit_meta, h->d_chi, h->d_chitot, h->d_meta);
+            HIPCHK(hipGetLastError());
+            h->last_literal_cells = n_lit;
+        }
+        if (h->h_recount[NS]) {
+            if (int rc = resolve_failed_cells(h, st, h->h_recount[NS])) return rc;
+        }
     }
     if (total)
         hipLaunchKernelGGL(k_scatter_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total,
@@ -2096,11 +2182,11 @@ static int spec_ensure(ipc_engine* h)
         if (h->dim == 3) {
             sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s3->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s3->reserve(h->V - 1, 256));
+            HIPCHK(sl.s3->reserve(h->V - 1, std::max(256, std::min(h->N + 1, 16384)), 256));
         } else {
             sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s2->d_abort_word = h->d_abort + q;
-            HIPCHK(sl.s2->reserve(h->V - 1, 256));
+            HIPCHK(sl.s2->reserve(h->V - 1, std::max(256, std::min(h->N + 1, 16384)), 256));
         }
     }
     if (!h->window_forced) {
@@ -2859,7 +2945,8 @@ extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, 
     HIPCHK(hipStreamSynchronize(nullptr));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bband_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * kLdsTotal)));
-    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, 0};
+    HIPCHK(hipMemset(ddinv + B.n + 32, 0, sizeof(double)));                 // (the word that holds 0.0)
+    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, ddinv + B.n + 32, 0};
     hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());

@@ -207,6 +207,10 @@ __device__ __forceinline__ void se2_wave_solve(const Se2View& P, int lo_abs, int
 #ifdef IPC_MB_DELAY_WAVE                               // (protocol stress: one wave of the cell dawdles behind every exchange)
             if (wsub == IPC_MB_DELAY_WAVE) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
 #endif
+            // Every lane polls the flag with an acquire load above, so every lane's payload reads are ordered behind the
+            // partner's release; the fence states that once more for the reads that follow, whatever the compiler makes of
+            // the loop (LDS only: a fence over global memory would wait for the constant prefetches in flight).
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             wave_sync();
         }
     };

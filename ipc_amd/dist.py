@@ -5,8 +5,8 @@ candidate list are replicated; rank r solves the cells (i, j >= i) of the rows t
 assignment gives it (ipc_row_assignment: balanced by cost -- a row's cost is the number of poses its
 cells sweep -- costliest row first to the least loaded rank; IPC_ROW_BALANCE=cyclic keeps i % world),
 producing bit rows [rows_per_rank, words] (row i sits at slot[i] % rows_per_rank of its owner's shard).
-ipc_solve_rows blocks the host twice (plan counts; cells to solve again, see include/ipc_amd.h) and
-returns with everything else enqueued.  ONE all-gather of those bit rows over xGMI reassembles the matrix on
+ipc_solve_rows blocks the host once per step (the counts of the cells to solve again; the first step of a candidate
+list once more for the plan, see include/ipc_amd.h) and returns with everything else enqueued.  ONE all-gather of those bit rows over xGMI reassembles the matrix on
 every rank (N^2/8 bytes in total: 197 KB for C2, 78 MB for C5), after which every rank
 assembles the symmetric matrix and runs the (cheap, sequential-in-k) set-max redundantly, so no
 second collective is needed to publish the result.
@@ -62,12 +62,15 @@ class EngineBackend:
 
 
 class ShardedMatrix:
-    def __init__(self, backend, rank=0, world=1, group=None):
+    def __init__(self, backend, rank=0, world=1, group=None, force_gather=False):
+        """force_gather: go through the collective even at world 1 (a 1-rank RCCL group on one GPU executes the same
+        all_gather_into_tensor call, stream ordering and tensor views as an 8-rank node does -- tests/test_gpu_dist_rccl.py)."""
         self.b, self.rank, self.world, self.group = backend, rank, world, group
+        self.gather = world > 1 or force_gather
         N, words = backend.N, backend.words
         self.rpr = (N + world - 1) // world
         self.upper = backend.empty_words(self.rpr * words)
-        self.gathered = backend.empty_words(world * self.rpr * words) if world > 1 else self.upper
+        self.gathered = backend.empty_words(world * self.rpr * words) if self.gather else self.upper
         self.bits = backend.empty_words(N * words)
         self.accepted = backend.empty_bytes(N)
 
@@ -77,7 +80,7 @@ class ShardedMatrix:
         ctx = self.b.stream_ctx() if hasattr(self.b, "stream_ctx") else contextlib.nullcontext()
         with ctx:
             self.b.solve_rows(self.rank, self.world, self.upper)
-            if self.world > 1:
+            if self.gather:
                 dist.all_gather_into_tensor(self.gathered, self.upper, group=self.group)
             self.b.assemble(self.gathered, self.world, self.bits)
             self.b.set_max(self.bits, self.accepted)

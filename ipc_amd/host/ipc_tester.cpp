@@ -1,6 +1,7 @@
 // ipc_tester_2D / ipc_tester_3D -- same CLI as the reference's examples/ipc_tester_{2D,3D}.cpp
 // ("-c <cfg.yaml>", examples/ipc_tester_2D.cpp:13-17), same config keys, same output files.
 // Built twice from this source with -DIPC_TESTER_DIM=2 / 3.
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
@@ -13,6 +14,9 @@
 
 int main(int argc, char** argv)
 {
+    // the faithful mode keeps 16 solves in flight, one per HIP stream: the runtime needs as many hardware queues, and reads
+    // this once, at its first call (include/ipc_amd.h "environment"; the host program's line, not the library's)
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
     std::string cfgFilename;
     for (int i = 1; i < argc; ++i)
         if (!std::strcmp(argv[i], "-c") && i + 1 < argc) cfgFilename = argv[++i];

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the host program's job (include/ipc_amd.h, "environment"): before the first HIP call of the process
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -187,6 +187,7 @@ static int run(const char* path, Config cfg, bool ref_order, bool in_graph)
 
 int main(int argc, char** argv)
 {
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);      // (the host program's line: INTEGRATION.md section 2; before the first HIP call)
     if (argc < 8) { std::fprintf(stderr, "usage: adapter_main dim file s fth fit sth sit [ref|stable] [graph|foreign] [canonic_inliers]\n"); return 2; }
     Config cfg;
     cfg.s_factor = std::atof(argv[3]);

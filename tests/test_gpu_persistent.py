@@ -614,3 +614,36 @@ def test_a_nan_edge_does_not_mask_an_edge_above_the_threshold(oracle):
     both = ~np.isnan(ref) & ~np.isnan(cells["max_chi2"])
     assert np.array_equal(np.isnan(ref), np.isnan(cells["max_chi2"]))
     assert (np.abs(cells["max_chi2"][both] - ref[both]) <= 1e-5 * np.maximum(np.abs(ref[both]), 1e-9)).all()
+
+
+def test_two_threads_with_an_engine_each_run_their_faithful_loops_side_by_side():
+    """Round 5 (ADVICE): a check on one engine stops the pipeline of the other (one pipeline per process), which the other
+    engine's owner thread may be pumping at that very moment.  Every call that touches pipeline state now holds one
+    process-wide lock for its whole duration: two threads that interleave their checks get, each, exactly the records of a
+    run on its own -- no lost candidate, no recycled tentative state."""
+    import threading
+    import bench
+    g, cfg, _ = bench.build_workload("tiny")
+    solo = _engine(g, cfg, "persist")
+    order = solo.candidate_order()
+    ref = _run(solo, order)
+    ref_poses = solo.current_poses().copy()
+    engs = [_engine(g, cfg, "persist") for _ in range(2)]
+    out, err = [None, None], [None, None]
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = _run(engs[i], order)
+        except Exception as e:                       # noqa: BLE001 -- reported by the asserting thread
+            err[i] = e
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert err == [None, None], err
+    for i in range(2):
+        _assert_bitwise(ref, out[i])
+        assert np.array_equal(ref_poses.view(np.uint64), engs[i].current_poses().view(np.uint64))
