@@ -41,6 +41,8 @@ struct BandLayout {
     __host__ __device__ __forceinline__ size_t at(int i, int j) const { return (size_t)j * ldb + (i < nb ? i - j : W + (i - nb)); }
     // is entry (i, j), i >= j, inside the stored profile?
     __host__ __device__ __forceinline__ bool in(int i, int j) const { return i >= nb || i - j < W; }
+    // the same address in 32 bits (a system holds < 2^31 doubles): one v_mad_u32 instead of a 64-bit multiply
+    __device__ __forceinline__ unsigned at32(int i, int j) const { return (unsigned)j * (unsigned)ldb + (unsigned)(i < nb ? i - j : W + (i - nb)); }
     __host__ __device__ size_t doubles() const { return (size_t)(n > 0 ? n : 1) * ldb + 64; }
 };
 // the rows below a block column that ends in front of column k1 and can hold a non-zero of it: band rows k1 .. and every
@@ -266,26 +268,30 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
     for (int s2 = 0; s2 < NS; ++s2) {
         const int c = s2 * LPR + q;
         const bool ok = c < nbk && pvalid && B.in(prow, k0 + c);
-        x[s2] = ld_shared(&A[ok ? B.at(prow, k0 + c) : (size_t)0]);
+        x[s2] = ld_shared(&A[ok ? B.at32(prow, k0 + c) : 0u]);
     }
     // the tile's old values do not depend on the panel solve: requested with the panel rows (one trip to memory for
     // both; they come from memory -- sc1 -- and a trip costs 2 - 4 us here, more than the solve and the product together)
     const TileOwn own{wv, lane};
     double old[16];
-    unsigned adr[16];                                          // (a system holds < 2^31 doubles)
     unsigned inmask = 0;
     const bool upd = has && j0v < TR.R - 1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    auto elem = [&](int e, unsigned& adr) -> bool {           // element e of this thread: inside the profile, and where
         const int iv = i0v + own.i_of(e), jv = j0v + own.j_of(e);
         const bool inr = upd && jv < TR.R - 1 && iv < TR.R && iv >= jv;
         const int i = TR.row(inr ? iv : 0), j = TR.row(inr ? jv : 0);
         bool in = inr && B.in(i, j);
         // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
         if (skip_next_diag && i < min(k1 + kCB, B.n)) in = false;
-        adr[e] = in ? (unsigned)B.at(i, j) : 0u;
+        adr = in ? B.at32(i, j) : 0u;
+        return in;
+    };
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        unsigned adr;
+        const bool in = elem(e, adr);
         inmask |= (in ? 1u : 0u) << e;
-        old[e] = ld_shared(&A[adr[e]]);
+        old[e] = ld_shared(&A[adr]);
     }
     after_loads();
     prof_add1(prof, kProfBsDots, ts0);
@@ -307,7 +313,7 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
                 const int c = s2 * LPR + q;
-                if (c < nbk && B.in(prow, k0 + c)) st_shared(&Lf[B.at(prow, k0 + c)], x[s2]);
+                if (c < nbk && B.in(prow, k0 + c)) st_shared(&Lf[B.at32(prow, k0 + c)], x[s2]);
             }
         }
     }
@@ -319,8 +325,11 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         double acc[16];
         tile_product(Ai, Aj, own, acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            if (inmask & (1u << e)) st_shared(&A[adr[e]], old[e] - acc[e]);
+        for (int e = 0; e < 16; ++e) {
+            unsigned adr;
+            elem(e, adr);
+            if (inmask & (1u << e)) st_shared(&A[adr], old[e] - acc[e]);
+        }
     }
     __syncthreads();
     prof_add1(prof, kProfHelpUpdate, tu0);

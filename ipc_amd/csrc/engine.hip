@@ -466,7 +466,7 @@ struct BinPlan {
 static const char* kDefaultPolicy = "w1,w3,w5,w7,w9,w11,w13,p7,p9,p11,q7,q9,q11,q13,16x4,16x8,16x16";
 // engine streams + the caller's stream = the runtime's four hardware queues for SE2; the long SE3
 // launches gain a little from a fourth engine stream
-static const int kDefaultSideStreams2 = 2, kDefaultSideStreams3 = 3;
+static const int kDefaultSideStreams2 = 7, kDefaultSideStreams3 = 7;      // (round 5: 2 / 3 until the side streams came from the process pool -- at 8 ranks a shard's bins hold fewer cells than the GPU has CUs and only concurrent launches fill it: C2 emulated 6.53x -> 7.07x, one rank unchanged)
 static const char* kDefaultPolicy3 = "w1,w2,w3,w4,w6,w8,g3,g4,g5,g6,g7,g8,g9,g10,16x4";
 static const char* kBlockPolicy3 = "1x1,1x2,1x3,2x2,2x3,4x2,4x4,8x4,8x5,16x4";   // round-1 block kernels only (IPC_SE3_POLICY=block)
 // SE3 variants for thin bins, by capacity (IPC_SE3_LATENCY_POLICY; "none" disables the switch)
@@ -596,6 +596,7 @@ struct ipc_engine {
     // The cell lists of (rank, world) change only with the candidates: the two planning passes and their read-back (the
     // first of ipc_solve_rows' two host waits) are paid once per candidate list, not once per step (round 5).
     bool plan_cached = false; int plan_rank = -1, plan_world = 0; size_t plan_total = 0;
+    int slow_first_iterations = 96;                    // IPC_SLOW_FIRST (0: off): cells that took this many iterations go to the head of their slot
     std::vector<unsigned> plan_counts, plan_offsets;
     // Borderline cells (borderline_band) are solved again with g2o's literal trial loop BY THE CELL KERNELS (term_eps 0)
     // over compact per-slot lists built on the device -- no per-cell copies, no host-driven solves (round 5).
@@ -855,6 +856,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
             }
         }
     }
+    if (const char* sf = getenv("IPC_SLOW_FIRST")) { if (*sf) h->slow_first_iterations = std::max(0, atoi(sf)); }
     if (const char* rb = getenv("IPC_ROW_BALANCE")) {
         if (!strcmp(rb, "cyclic")) h->row_policy = 0;
         else if (*rb && strcmp(rb, "cost")) { delete h; return fail(IPC_ERR_ARG, "IPC_ROW_BALANCE must be 'cost' or 'cyclic'"); }
@@ -1423,6 +1425,54 @@ __global__ void k_collect_failed(int ncells, const int4* meta, const double* chi
         lit_idx[slot_off[sl] + q] = c;
     }
 }
+// ---- slow cells first (round 5) ---------------------------------------------------------------------------------
+// A bin's launch draws cells from the head of its list; a cell that runs to the iteration cap (500 iterations against a
+// mean of ~30: ~10 ms on a 1000-pose chain) and is drawn late IS the tail of the launch -- nothing on one GPU, whose CUs
+// always find other work, but 15 - 20 % of a step once the rows are spread over 8 ranks (54 ms of work per rank).  Which
+// cells are slow is known exactly after one solve of the list: the step that plans a candidate list ends by moving the
+// cells that took >= slow_first_iterations iterations to the head of their slot, everything else keeps its order (sorted by
+// chain position: L2 locality).  Results move with their cells; every cell's arithmetic is unchanged.
+__global__ void k_slow_flags(int ncells, const int4* meta, int threshold, int* normal)     // normal[c] = 1: stays behind the slow cells
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= ncells) normal[c] = (c < ncells && meta[c].x < threshold) ? 1 : 0;
+}
+// in-place exclusive prefix sum of n ints, one workgroup
+__global__ __launch_bounds__(1024) void k_scan_int(int* a, int n)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v0 = i < n ? a[i] : 0;
+        int v = v0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int off = carry, tot = carry;
+        for (int w = 0; w < 16; ++w) { if (w < wave) off += wsum[w]; tot += wsum[w]; }
+        if (i < n) a[i] = off + v - v0;
+        carry = tot;
+        __syncthreads();
+    }
+}
+__global__ void k_slow_first_permute(int ncells, const unsigned* slot_off, int nslots, const int* excl_normal, const int2* cells,
+                                     const double* chi, const double* chitot, const int4* meta, int2* cells2, double* chi2,
+                                     double* chitot2, int4* meta2)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int sl = slot_of_cell(slot_off, nslots, c);
+    const int s0 = (int)slot_off[sl], s1 = (int)slot_off[sl + 1];
+    const int n0 = excl_normal[s0], nc = excl_normal[c], n1 = excl_normal[s1];
+    const bool normal = excl_normal[c + 1] != nc;
+    const int nslow = (s1 - s0) - (n1 - n0);
+    const int dst = normal ? s0 + nslow + (nc - n0) : s0 + ((c - s0) - (nc - n0));
+    cells2[dst] = cells[c]; chi2[dst] = chi[c]; chitot2[dst] = chitot[c]; meta2[dst] = meta[c];
+}
+
 // the literal re-solves back to where their cells sit
 __global__ void k_scatter_literal(int ncells, const unsigned* slot_off, int nslots, const int* recount, const int* lit_idx,
                                   const double* lit_chi, const double* lit_chitot, const int4* lit_meta, double* chi, double* chitot, int4* meta)
@@ -1671,6 +1721,18 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
                            h->d_cells, h->d_chi, h->prm.fast_reject_th, h->prm.slow_reject_th, rpr, (const int*)h->d_slot, words,
                            (unsigned long long*)d_upper);
     HIPCHK(hipGetLastError());
+    if (total && !cached && phase == 0 && h->slow_first_iterations > 0) {
+        // this step built the cell lists: its iteration counts order them for the steps to come (slow cells first)
+        const unsigned nblk1 = (unsigned)((total + 1 + 255) / 256), nblk = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(k_slow_flags, dim3(nblk1), dim3(256), 0, st, (int)total, (const int4*)h->d_meta, h->slow_first_iterations, h->d_lit_idx);
+        hipLaunchKernelGGL(k_scan_int, dim3(1), dim3(1024), 0, st, h->d_lit_idx, (int)total + 1);
+        hipLaunchKernelGGL(k_slow_first_permute, dim3(nblk), dim3(256), 0, st, (int)total, (const unsigned*)h->d_slot_off, NS, (const int*)h->d_lit_idx,
+                           (const int2*)h->d_cells, (const double*)h->d_chi, (const double*)h->d_chitot, (const int4*)h->d_meta, h->d_lit_cells,
+                           h->d_lit_chi, h->d_lit_chitot, h->d_lit_meta);
+        HIPCHK(hipGetLastError());
+        std::swap(h->d_cells, h->d_lit_cells); std::swap(h->d_chi, h->d_lit_chi);
+        std::swap(h->d_chitot, h->d_lit_chitot); std::swap(h->d_meta, h->d_lit_meta);
+    }
     return IPC_OK;
 }
 
@@ -2950,6 +3012,30 @@ extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, 
     hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
+    if (const char* reps_env = getenv("IPC_BAND_SOLVE_REPS")) {          // (tuning: the factorisation + back substitution alone, timed)
+        const int reps = std::max(1, atoi(reps_env));
+        double* dA0 = nullptr;
+        HIPCHK(hipMalloc(&dA0, sizeof(double) * sz));
+        HIPCHK(hipMemset(dA0, 0, sizeof(double) * sz));
+        HIPCHK(hipMemcpy(dA0, system, sizeof(double) * (size_t)B.n * B.ldb, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        float total_ms = 0.f;
+        for (int r = 0; r < reps; ++r) {
+            HIPCHK(hipMemcpyAsync(dA, dA0, sizeof(double) * sz, hipMemcpyDeviceToDevice, nullptr));
+            HIPCHK(hipMemsetAsync(dctl, 0, sizeof(PersistCtl), nullptr));
+            HIPCHK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
+            HIPCHK(hipEventRecord(e1, nullptr));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+        }
+        fprintf(stderr, "[band solve] n %d W %d m %d workgroups %d: %.1f us per factorisation + back substitution (%d block columns, %.2f us each)\n",
+                B.n, B.W, B.m, workgroups, 1e3 * total_ms / reps, (B.n + kCB - 1) / kCB, 1e3 * total_ms / reps / ((B.n + kCB - 1) / kCB));
+        hipEventDestroy(e0); hipEventDestroy(e1); hipFree(dA0);
+    }
     HIPCHK(hipMemcpy(x_out, dx, sizeof(double) * B.n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(info_out, dinfo, sizeof(int), hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(ddinv); hipFree(dinfo); hipFree(dctl);

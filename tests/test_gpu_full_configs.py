@@ -281,3 +281,72 @@ def test_c5_row_shards_of_eight_ranks_reassemble_to_the_single_gpu_matrix():
     total = sum(per_rank)
     assert max(per_rank) <= 1.25 * total / world, per_rank         # solved cells per rank: the cost balance holds on SE3 too
     print("C5, 8 ranks: solved cells per rank", per_rank)
+
+
+def test_a_wide_borderline_band_costs_a_fraction_of_a_step(monkeypatch):
+    """Round 5: the borderline cells are solved again by the cell kernels themselves over compact lists built on the device
+    (no per-cell host copies, no host-driven solves).  With the band opened to 5 % (hundreds of literal cells on C1) a
+    step stays within 1.5 x of the default step; the literal cells carry the bits of a run with the convergence test off."""
+    import time
+    from bench import build_workload
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = build_workload("C1")
+
+    def timed(env):
+        for k in ("IPC_TERMINATE_EPS", "IPC_BORDERLINE_BAND"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = IPC(g, cfg, device=0)
+        eng.run()                                    # plan, buffers, code objects
+        eng.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            bits, acc = eng.run()
+            ts.append(time.perf_counter() - t0)
+        c = eng.cell_info()
+        rep = eng.solve_report()
+        eng.close()
+        return float(np.median(ts)), bits, acc, c[np.lexsort((c["j"], c["i"]))], rep
+
+    t_def, b_def, a_def, c_def, r_def = timed({})
+    t_wide, b_wide, a_wide, c_wide, r_wide = timed({"IPC_BORDERLINE_BAND": "0.05"})
+    t_lit, b_lit, a_lit, c_lit, _ = timed({"IPC_TERMINATE_EPS": "0"})
+    assert r_wide["literal_cells"] >= 100, r_wide
+    print("\n[borderline band 5 %%] %d literal cells, step %.1f ms against %.1f ms by default" % (r_wide["literal_cells"], 1e3 * t_wide, 1e3 * t_def))
+    assert t_wide <= 1.5 * t_def, (t_wide, t_def)
+    assert np.array_equal(b_wide, b_lit) and np.array_equal(a_wide, a_lit)
+    th = np.where(c_def["i"] == c_def["j"], cfg.fast_reject_th, cfg.slow_reject_th)
+    near = np.abs(c_def["max_chi2"] - th) <= 0.05 * th
+    assert int(near.sum()) == r_wide["literal_cells"]
+    assert np.array_equal(c_wide["max_chi2"][near].view(np.uint64), c_lit["max_chi2"][near].view(np.uint64))
+    assert np.array_equal(c_wide["iterations"][near], c_lit["iterations"][near])
+
+
+def test_repeated_steps_reuse_the_cell_lists_and_an_appended_candidate_renews_them():
+    """ipc_solve_rows keeps the cell lists of (rank, world) between steps (one host wait per step instead of two); the lists
+    are rebuilt when the candidates change (ipc_append_candidate), when another rank's rows are asked for, and by the
+    set-only phases, which plan from the step's diagonal bits."""
+    from bench import build_workload
+    from ipc_amd import synth
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = build_workload("tiny")
+    eng = IPC(g, cfg, device=0)
+    b0, a0 = eng.run()
+    for _ in range(3):
+        b, a = eng.run()
+        assert np.array_equal(b, b0) and np.array_equal(a, a0)
+    acc_so, _ = eng.run_set_only()
+    assert np.array_equal(acc_so, a0)
+    b, a = eng.run()
+    assert np.array_equal(b, b0) and np.array_equal(a, a0)
+    # one more candidate: the matrix of the longer list = a fresh engine on that list
+    extra = synth.inject_outliers(g, 1, seed=77)
+    k = eng.append_candidate(extra.loop_ids[-1], extra.loop_meas[-1], extra.loop_info[-1])
+    assert k == g.N
+    b1, a1 = eng.run()
+    ref = IPC(extra, cfg, device=0)
+    br, ar = ref.run()
+    assert np.array_equal(b1, br) and np.array_equal(a1, ar)
+    eng.close(); ref.close()

@@ -198,3 +198,55 @@ def test_final_map_se3_matches_oracle(oracle):
     assert abs(inf.max_chi2 - ref["max_chi2"]) <= REL * max(ref["max_chi2"], 1e-12)
     assert np.allclose(poses[:, 9:], ref["poses"][:, 9:], rtol=0, atol=1e-6)
     assert _rot_angle(poses[:, :9], ref["poses"][:, :9]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("workload", ["C5", "T2400"])
+def test_tail_after_accepts_matches_the_serial_compose_on_long_chains(workload):
+    """k_apply_accept rebuilds the tail behind an accepted window as ONE rigid transform of the open-loop poses
+    (D = T (+) P^-1, round 4) where the reference composes pose by pose (propagateCurrentGuess, src/consensus_utils.cpp:61-71).
+    On long tails (V = 50 000 SE3, V = 2 400 SE2) after several accepts: equal to the oracle's serial compose to 1e-12 of
+    the trajectory's extent, and the SE3 rotations stay orthonormal (two unnormalised 3 x 3 products per accept)."""
+    import bench
+    from ipc_amd.consensus import IPC
+    from oracle import oracle as O
+    g, cfg, _ = bench.build_workload(workload)
+    eng = IPC(g, cfg, device=0)
+    inc = O.IncrementalIPC(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                           cfg.slow_reject_th, cfg.slow_reject_iter_base, g.loop_ids, g.loop_meas, g.loop_info)
+    order = eng.candidate_order()
+    eng.reset()
+    accepts = 0
+    for k in order[:400]:
+        ok = eng.agreementCheck(int(k))
+        ok_ref, _ = inc.agreement_check(int(k))
+        assert ok == ok_ref
+        accepts += ok
+        if accepts >= 6:
+            break
+    assert accepts >= 3
+    # behind the last accepted window the trajectory is pure odometry: pose i = pose i-1 (+) z_{i-1}, whatever the window's
+    # own poses are (those agree with the oracle's to solver tolerance only)
+    got = eng.current_poses()
+    hi_last = int(max(g.loop_ids[int(c)].max() for c in eng.getMaxConsensusSet()))
+    idx = np.arange(hi_last + 1, g.V)
+    assert len(idx) > 1000
+    if g.dim == 3:
+        from ipc_amd.synth import _quat_to_R
+        R = got[:, :9].reshape(-1, 3, 3)
+        t = got[:, 9:]
+        extent = np.abs(t).max()
+        Rz = np.stack([_quat_to_R(q / np.linalg.norm(q)) for q in g.odom_meas[idx - 1, 3:]])
+        t_pred = t[idx - 1] + np.einsum("nij,nj->ni", R[idx - 1], g.odom_meas[idx - 1, :3])
+        R_pred = np.einsum("nij,njk->nik", R[idx - 1], Rz)
+        assert np.abs(t[idx] - t_pred).max() <= 2e-12 * max(extent, 1.0), np.abs(t[idx] - t_pred).max()
+        assert np.abs(R[idx] - R_pred).max() <= 1e-12
+        assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() <= 1e-12
+    else:
+        x, y, th = got[:, 0], got[:, 1], got[:, 2]
+        extent = max(np.abs(x).max(), np.abs(y).max())
+        z = g.odom_meas[idx - 1]
+        c, s_ = np.cos(th[idx - 1]), np.sin(th[idx - 1])
+        assert np.abs(x[idx] - (x[idx - 1] + c * z[:, 0] - s_ * z[:, 1])).max() <= 2e-12 * max(extent, 1.0)
+        assert np.abs(y[idx] - (y[idx - 1] + s_ * z[:, 0] + c * z[:, 1])).max() <= 2e-12 * max(extent, 1.0)
+        assert np.abs(np.angle(np.exp(1j * (th[idx] - th[idx - 1] - z[:, 2])))).max() <= 1e-12
+    eng.close()

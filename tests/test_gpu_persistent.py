@@ -647,3 +647,39 @@ def test_two_threads_with_an_engine_each_run_their_faithful_loops_side_by_side()
     for i in range(2):
         _assert_bitwise(ref, out[i])
         assert np.array_equal(ref_poses.view(np.uint64), engs[i].current_poses().view(np.uint64))
+
+
+def test_idle_engines_do_not_slow_the_faithful_run_down():
+    """Round 5: an engine owns ONE stream (its matrix-mode side streams come from the process's per-device pool, the one
+    the pipeline's slots use), so three more live engines no longer push the process past the couple of dozen streams the
+    runtime runs side by side (round 4: C1 0.55 s alone, 0.68 s with three idle engines alive)."""
+    import time
+    import bench
+    g, cfg, _ = bench.build_workload("C1")
+
+    def best_of(eng, reps=5):
+        order = eng.candidate_order()
+        best = 1e30
+        for _ in range(reps):
+            eng.reset()
+            eng.agreementCheck(int(order[0]))
+            eng.reset()
+            eng.synchronize()
+            t0 = time.perf_counter()
+            for k in order:
+                eng.agreementCheck(int(k))
+            eng.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    eng = _engine(g, cfg, "persist")
+    solo = best_of(eng)
+    idle = [_engine(g, cfg, "persist") for _ in range(3)]
+    for e in idle:
+        e.run()                                      # (they have worked: streams, buffers and code objects are there)
+    crowded = best_of(eng)
+    print("\n[C1 faithful run] alone %.3f s, with three idle engines alive %.3f s" % (solo, crowded))
+    assert crowded <= 1.10 * solo, (solo, crowded)
+    for e in idle:
+        e.close()
+    eng.close()
