@@ -317,7 +317,7 @@ def executed_flops(workload, dim):
     counts: x 64 lanes, FMA = 2 flops).  `current` says whether the pass was taken on the kernel sources of this build
     (sidecar .meta.json written by tools/r4_profile.sh sq; passes without one predate the check).  None: no such file."""
     import csv
-    for rnd in ("r4", "r3", "r2"):
+    for rnd in ("r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.csv" % (rnd, workload.lower()))
         if os.path.exists(path):
             break
@@ -414,9 +414,10 @@ def main():
     # (FETCH_SIZE / WRITE_SIZE in KB, separate passes; FETCH_SIZE doubled per the gfx950 note in
     # MI355X_MICROARCH.md).  Per step, like `achieved`.
     traffic = None
-    pmc_csv = os.path.join(ROOT, "profiles", "r4_pmc_hbm_%s.csv" % args.workload)
-    if not os.path.exists(pmc_csv):
-        pmc_csv = os.path.join(ROOT, "profiles", "pmc_hbm_%s.csv" % args.workload)
+    for rnd in ("r5_", "r4_", ""):
+        pmc_csv = os.path.join(ROOT, "profiles", "%spmc_hbm_%s.csv" % (rnd, args.workload))
+        if os.path.exists(pmc_csv):
+            break
     if os.path.exists(pmc_csv) and world == 1:
         import csv
         f = w = 0.0

@@ -701,7 +701,7 @@ struct ipc_engine {
     // and whose verdict is still out will most likely be thrown away, so at most spec_behind of them are started; in
     // front of it everything in flight is useful and the window may be as wide as the CUs allow.
     std::vector<char> pred_accept;                     // by candidate: 1 = expected to be accepted (IPC_SPEC_PREDICT_FILE: a recorded run, experiments)
-    double pred_k = 10.0;                              // predicted accept: own chi2 at the state it starts from <= pred_k x the slow threshold (IPC_SPEC_PREDICT; 0: off)
+    double pred_k = 30.0;                              // predicted accept: own chi2 at the state it starts from <= pred_k x the slow threshold (IPC_SPEC_PREDICT; 0: off; 10 until round 5: on C5 a third of the mispredicted accepts -- each drops the ~15 solves in flight behind it -- lie between 10 and 30, C5 prefix 23.0 -> 21.5 s, C2 and C4 unchanged)
     std::vector<double> pred_last;                     // the newest predictions that have arrived (stand-in while a state's own are on their way)
     int spec_behind = 1;                               // IPC_SPEC_BEHIND (C1: 0.56 / 0.59 / 0.59 / 0.63 s with 0 / 1 / 2 / 4 -- every launch is host time on the accept chain; C2, C4m: within noise)
     int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
