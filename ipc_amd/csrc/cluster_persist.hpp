@@ -780,7 +780,7 @@ struct PersistSe3 {
     __device__ static void bHb_psi(const Dev& D, int i, double (&v)[1]) { gk3_bHb_psi_at(D, i, v); }
     __device__ static void assemble(const Dev& D, int l1, int l2) { gk3_assemble_at(D, l1, l2); }
     template <class Put, class PutRhs>
-    __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk3_assemble_core_wide(D, l1, l2, put, put_rhs); }
+    __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk3_assemble_core(D, l1, l2, put, put_rhs); }
     __device__ static void nu(const Dev& D, int l) { gk3_nu_at(D, l); }
     __device__ static void events(const Dev& D, int j) { gk3_events_at(D, j); }
     __device__ static void rho(const Dev& D, int i) { gk3_rho_at(D, i); }

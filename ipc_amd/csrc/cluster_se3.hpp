@@ -342,65 +342,6 @@ __device__ __forceinline__ void gk3_assemble_core(const ClusterDev3& D, int l1, 
         }
     }
 }
-// The same block with every operand requested up front (Gamma_l1, Gamma_l2, the prefix-sum differences: ~120 loads in
-// flight, one trip to L2) and the products fully unrolled -- the arithmetic and its order are gk3_assemble_core's, so the
-// values are the same bits.  The rolled form above costs a dependent L2 round trip per row and column of the block
-// (~40 us per block pair): nothing in the dense kernel, where a few hundred threads share the pairs, 10 % of an iteration
-// in the banded kernel, whose ~4 600 threads each walk through a dozen pairs.  Needs ~150 registers.
-template <class Put, class PutRhs>
-__device__ __forceinline__ void gk3_assemble_core_wide(const ClusterDev3& D, int l1, int l2, Put put, PutRhs put_rhs)
-{
-    if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
-    const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
-    const int lo2 = min(D.lfrom[l2], D.lto[l2]), hi2 = max(D.lfrom[l2], D.lto[l2]);
-    const int a = max(lo1, lo2), bq = min(hi1, hi2);
-    const bool ov = bq > a;
-    const int ia = ov ? a : 0, ib = ov ? bq : 0;
-    double Pa[21], Pb[21], G1[36], G2[36];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) { Pb[k] = gptr(D.ps)[(size_t)k * D.ld + ib]; Pa[k] = gptr(D.ps)[(size_t)k * D.ld + ia]; }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) { G1[k] = gptr(D.gam)[(size_t)k * D.nl + l1]; G2[k] = gptr(D.gam)[(size_t)k * D.nl + l2]; }
-    double sgl[21], wl[6], wh[6], le6[6];
-    const bool diag = l1 == l2;
-    if (diag) {
-        gk3_sym(D.cand, D.cstride, G_SG, D.lcand[l1], sgl);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            wh[q] = gptr(D.ps)[(size_t)(21 + q) * D.ld + hi1]; wl[q] = gptr(D.ps)[(size_t)(21 + q) * D.ld + lo1];
-            le6[q] = gptr(D.le)[(size_t)q * D.nl + l1];
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    double Mm[21];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) Mm[k] = ov ? Pb[k] - Pa[k] : 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        double T[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            double acc = 0.0;
-#pragma unroll
-            for (int p = 0; p < 6; ++p) acc += G1[6 * r + p] * Mm[sym6_idx(p, q)];
-            T[q] = acc;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) acc += T[q] * G2[6 * c + q];
-            if (diag) acc += sgl[sym6_idx(r, c)];
-            put(6 * l1 + r, 6 * l2 + c, acc);
-        }
-        if (diag) {
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) acc += G1[6 * r + q] * (wh[q] - wl[q]);
-            put_rhs(6 * l1 + r, le6[r] - acc);
-        }
-    }
-}
 __device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, int l2)
 {
     const int NS = 6 * D.nl;
