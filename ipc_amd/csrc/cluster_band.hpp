@@ -505,9 +505,15 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
 // L^T x = y (y = the last dense row of the factor), workgroup 0 only: cluster_persist.hpp::pchol_backsolve on the banded
 // layout.  Per block column (from the last): the dots with the already solved unknowns run over the rows of the column's
 // profile (BandRows without the right-hand side), their factor entries requested one block column ahead.
+// Two block columns' worth of factor entries are kept in flight (two register buffers, used alternately): a step's
+// arithmetic is ~1 us, a trip to memory 3 - 4, and one buffer ahead left every step waiting for its operands.
+struct BandBsBuf {
+    static constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 8, DPT = (kCB * kCB + kPT - 1) / kPT;
+    double pre[CPW][MAXM], dpre[DPT], ypre;
+};
 __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout B, double* x, double* lds, const double* zero)
 {
-    constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 12, DPT = (kCB * kCB + kPT - 1) / kPT;
+    constexpr int NW = BandBsBuf::NW, CPW = BandBsBuf::CPW, MAXM = BandBsBuf::MAXM, DPT = BandBsBuf::DPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
     double* t = lds + kLdsDinv;
     double* xs = lds + kLdsR;
@@ -515,10 +521,9 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
     const bool x_in_lds = n <= kPSG * 2 * kLdsPanel;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31;
     const int nblk = (n + kCB - 1) / kCB;
-    double pre[CPW][MAXM], dpre[DPT], ypre = 0.0;
     // entry (r, j) sits at j * (ldb - 1) + r for a band row, at j * ldb + (W - nb) + r for a dense row; entries outside
     // the profile are read from a word that holds 0.0, so the dots below need no mask
-    auto prefetch = [&](int kb) {
+    auto prefetch = [&](int kb, BandBsBuf& Q) {
         const int k0 = kb * kCB, nbk = min(kCB, n - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
@@ -539,19 +544,20 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
 #pragma unroll
                 for (int q = 0; q < CPW; ++q) {
                     const bool ok = v < Rm && (dense || r - jc[q] < B.W);
-                    pre[q][m] = ld_shared(ok ? &Lf[(dense ? jd[q] : jb[q]) + (unsigned)r] : zero);
+                    Q.pre[q][m] = ld_shared(ok ? &Lf[(dense ? jd[q] : jb[q]) + (unsigned)r] : zero);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
-            dpre[q] = ld_shared(&Lf[(idx < kCB * kCB && r < nbk && c < nbk && r >= c) ? B.at(k0 + r, k0 + c) : (size_t)0]);
+            Q.dpre[q] = ld_shared(&Lf[(idx < kCB * kCB && r < nbk && c < nbk && r >= c) ? B.at32(k0 + r, k0 + c) : 0u]);
         }
-        ypre = ld_shared(&Lf[l < nbk ? B.at(n, k0 + l) : (size_t)0]);
+        Q.ypre = ld_shared(&Lf[l < nbk ? B.at32(n, k0 + l) : 0u]);
     };
-    prefetch(nblk - 1);
-    for (int kb = nblk - 1; kb >= 0; --kb) {
+    // one block column: the dots with the solved unknowns, then (nxt >= 0) the request for block column nxt into the
+    // buffer this step has just emptied, then the triangle
+    auto step = [&](int kb, BandBsBuf& Q, int nxt) {
         const int k0 = kb * kCB, nbk = min(kCB, n - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
@@ -562,7 +568,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
             if (64 * m < Rm) {                                // (wave-uniform)
                 const int v = lane + 64 * m;
                 const int rc = v < Rm ? TR.row(v) : -1;
-                const double xv = x_in_lds ? xs[rc >= 0 ? rc : 0] : gptr(x)[rc >= 0 ? rc : 0];
+                const double xv = x_in_lds ? xs[rc >= 0 ? rc : 0] : ld_shared(&x[rc >= 0 ? rc : 0]);     // (beyond LDS: sc1 both ways, no reliance on this CU's L1)
                 xr[m] = rc >= 0 ? xv : 0.0;
             }
         }
@@ -574,10 +580,10 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
                 double acc = 0.0;
 #pragma unroll
                 for (int m = 0; m < MAXM; ++m)
-                    if (64 * m < Rm) acc += pre[q][m] * xr[m];
-                for (int v = lane + 64 * MAXM; v < Rm; v += 64) {
+                    if (64 * m < Rm) acc += Q.pre[q][m] * xr[m];
+                for (int v = lane + 64 * MAXM; v < Rm; v += 64) {     // (profiles beyond 512 rows)
                     const int r = TR.row(v);
-                    if (B.in(r, k0 + c)) acc += ld_shared(&Lf[B.at(r, k0 + c)]) * gptr(x)[r];
+                    if (B.in(r, k0 + c)) acc += ld_shared(&Lf[B.at32(r, k0 + c)]) * (x_in_lds ? xs[r] : ld_shared(&x[r]));
                 }
                 acc = wave_sum(acc);
                 t[c] = acc;
@@ -586,10 +592,10 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
-            if (idx < kCB * kCB) D[r][c] = (r < nbk && c < nbk && r >= c) ? dpre[q] : (r == c ? 1.0 : 0.0);
+            if (idx < kCB * kCB) D[r][c] = (r < nbk && c < nbk && r >= c) ? Q.dpre[q] : (r == c ? 1.0 : 0.0);
         }
-        const double ycur = ypre;
-        if (kb > 0) prefetch(kb - 1);
+        const double ycur = Q.ypre;
+        if (nxt >= 0) prefetch(nxt, Q);
         __syncthreads();
         if (wave == 0) {
             double v = l < nbk ? ycur - t[l] : 0.0;
@@ -603,12 +609,19 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
                 v = l == r ? xq : (l < r ? fma(-col[r], xq, v) : v);
             }
             if (lane < nbk) {
-                gptr(x)[k0 + lane] = v;
+                st_shared(&x[k0 + lane], v);
                 if (x_in_lds) xs[k0 + lane] = v;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (x is read back from memory by the other waves when it is not in LDS)
+        if (!x_in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (x is read back from memory by the other waves when it is not in LDS)
         __syncthreads();
+    };
+    BandBsBuf Qa, Qb;
+    prefetch(nblk - 1, Qa);
+    if (nblk >= 2) prefetch(nblk - 2, Qb);
+    for (int kb = nblk - 1; kb >= 0; kb -= 2) {
+        step(kb, Qa, kb - 2);
+        if (kb >= 1) step(kb - 1, Qb, kb - 3);
     }
 }
 

@@ -74,7 +74,7 @@ def _random_system(nb, m, W, seed):
 
 @pytest.mark.parametrize("nb,m,W,wgs", [(0, 7, 64, 1), (0, 40, 64, 3), (33, 1, 64, 1), (100, 1, 64, 2), (500, 7, 66, 1),
                                         (500, 7, 66, 5), (1000, 13, 300, 12), (3000, 7, 126, 6), (2000, 65, 192, 9),
-                                        (2000, 65, 192, 1), (777, 19, 90, 4)])
+                                        (2000, 65, 192, 1), (777, 19, 90, 4), (2500, 7, 600, 8)])
 def test_band_solve_against_numpy(nb, m, W, wgs):
     from ipc_amd import capi
     lib = capi.load()
@@ -88,6 +88,43 @@ def test_band_solve_against_numpy(nb, m, W, wgs):
     ref = np.linalg.solve(S, rhs)
     assert np.abs(x - ref).max() <= 1e-10 * np.linalg.cond(S) * max(1.0, np.abs(ref).max()), np.abs(x - ref).max()
     assert np.abs(S @ x - rhs).max() <= 1e-11 * np.abs(S).sum(axis=1).max() * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("nb,m,W,wgs", [(9000, 7, 66, 4), (17000, 13, 130, 6), (30000, 7, 252, 9)])
+def test_band_solve_of_systems_beyond_the_lds_resident_solution(nb, m, W, wgs):
+    """Beyond 8 320 unknowns the back substitution keeps x in memory instead of LDS (C5's clusters: 20 000 unknowns).
+    Diagonally dominant banded + bordered systems built directly in the packed layout; residual against a sparse product."""
+    import scipy.sparse as sp
+    from ipc_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(nb + m)
+    n = nb + m - 1
+    ldb = W + m
+    packed = np.zeros((n, ldb))
+    rows, cols, vals = [], [], []
+    for j in range(n):
+        if j < nb:
+            hi = min(nb, j + W)
+            packed[j, 1:hi - j] = rng.normal(0, 0.3 / W, hi - j - 1)
+            rows.append(np.arange(j + 1, hi)); cols.append(np.full(hi - j - 1, j)); vals.append(packed[j, 1:hi - j].copy())
+        d0 = max(nb, j + 1)
+        if d0 < n:
+            packed[j, W + d0 - nb:W + m - 1] = rng.normal(0, 0.3 / n, n - d0)
+            rows.append(np.arange(d0, n)); cols.append(np.full(n - d0, j)); vals.append(packed[j, W + d0 - nb:W + m - 1].copy())
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    Lo = sp.csr_matrix((v, (r, c)), shape=(n, n))
+    diag = 1.0 + rng.uniform(0, 1, n)                       # (off-diagonal row sums stay below 1: SPD by Gershgorin)
+    for j in range(n):
+        packed[j, 0 if j < nb else W + j - nb] = diag[j]
+    S = Lo + Lo.T + sp.diags(diag)
+    rhs = rng.normal(0, 1, n)
+    packed[:, W + m - 1] = rhs
+    packed = np.ascontiguousarray(packed)
+    x = np.zeros(n)
+    info = C.c_int(0)
+    capi.check(lib.ipc_debug_band_solve(nb, m, W, packed.ctypes.data_as(C.c_void_p), wgs, x.ctypes.data_as(C.c_void_p), C.byref(info)))
+    assert info.value == 0
+    assert np.abs(S @ x - rhs).max() <= 1e-11 * max(1.0, np.abs(x).max())
 
 
 def test_band_solve_is_independent_of_the_workgroup_count():
