@@ -26,7 +26,7 @@
 //    loads and stores; per-XCD L2s are not coherent with each other) -- about 5 us each, ~25 per iteration, against
 //    a factorisation of milliseconds at these sizes.  The results do not depend on the number of workgroups.
 //
-// Clusters below IPC_BAND_MIN_N unknowns (default 2 048) keep the dense persistent kernel, bit for bit as before.
+// Clusters below IPC_BAND_MIN_N unknowns (default 1 024) keep the dense persistent kernel, bit for bit as before.
 #pragma once
 
 namespace ipc {

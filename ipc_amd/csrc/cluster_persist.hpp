@@ -1048,8 +1048,9 @@ public:
     int launch_id = 0;
     int max_helpers = 39;                       // workgroups besides the leader (kLdsTotal = 141 824 bytes of LDS each: one per CU)
     // clusters of at least this many capacitance unknowns whose loops form a band go to cluster_band_kernel
-    // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it: the dense kernel, bit for bit as in rounds 3-4.
-    int band_min_n = 2048;
+    // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it (C1's 759, C2's 480 unknowns): the dense kernel, bit for bit as in rounds 3-4.
+    int band_min_n = 1024;                      // (2 048 in the first round-5 runs: C4's first 700 candidates 5.6 s -> 3.9 s; at 1 000 unknowns the dense
+                                                // trailing update is already several rounds of tiles per block column, the band's is one)
 
     PersistSolver()
     {

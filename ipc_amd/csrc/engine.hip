@@ -609,6 +609,7 @@ struct ipc_engine {
     // launch (a few cells that run to the iteration cap) overlaps the next bins
     static constexpr int kMaxSide = 7;
     int n_side = 0;
+    bool side_forced = false;                          // IPC_SIDE_STREAMS given: used as is, whatever the size of the step
     hipStream_t side[kMaxSide] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {}, ev_join_own = nullptr;
     // scratch for ipc_run
@@ -886,6 +887,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     {
         const char* env = getenv("IPC_SIDE_STREAMS");
         h->n_side = env && *env ? atoi(env) : (h->dim == 2 ? kDefaultSideStreams2 : kDefaultSideStreams3);
+        h->side_forced = env && *env;
         if (h->n_side < 0) h->n_side = 0;
         if (h->n_side > ipc_engine::kMaxSide) h->n_side = ipc_engine::kMaxSide;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1636,18 +1638,23 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
     // hardware queues); a caller's stream only forks and joins.  Launching a share of the bins on a
     // caller's stream made the overlap depend on which hardware queue that stream happened to be
     // mapped to (T700 on a torch pool stream: 51 ms instead of 32 ms).
-    hipStream_t st0 = h->n_side ? h->own_stream : st;
-    if (h->n_side) {
+    // Lanes for the bin launches: all seven side streams while the step is small (a shard of an 8-rank run, a thinned graph:
+    // bins with fewer cells than the GPU has CUs only fill it side by side), two (SE2) / three (SE3) for large steps, whose
+    // bins fill the GPU on their own and whose long-chain kernels lose to each other's traffic (C4, 3.2 M cells: 41.6 s with
+    // three lanes, 43.6 s with seven; C2 is indifferent).
+    const int n_side = h->side_forced || total < 300000 ? h->n_side : std::min(h->n_side, h->dim == 2 ? 2 : 3);
+    hipStream_t st0 = n_side ? h->own_stream : st;
+    if (n_side) {
         HIPCHK(hipEventRecord(h->ev_fork, st));
         if (st0 != st) HIPCHK(hipStreamWaitEvent(st0, h->ev_fork, 0));
-        for (int k = 0; k < h->n_side; ++k) HIPCHK(hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
+        for (int k = 0; k < n_side; ++k) HIPCHK(hipStreamWaitEvent(h->side[k], h->ev_fork, 0));
     }
     for (int b = nb - 1; b >= 0; --b) {
         for (int nl = 2; nl >= 1; --nl) {
             const int s = (nl == 1 ? 0 : (kMaxBins + 1)) + b;
             if (!counts[s]) continue;
             CellOut out{h->d_chi + offsets[s], h->d_chitot + offsets[s], h->d_meta + offsets[s]};
-            const int lane_q = launches % (h->n_side + 1);
+            const int lane_q = launches % (n_side + 1);
             hipStream_t ls = lane_q == 0 ? st0 : h->side[lane_q - 1];
             const hipError_t e = launch_slot(b, nl, (int)counts[s], h->d_cells + offsets[s], out, ls, h->d_wave_ctr + s);
             if (e != hipSuccess) return fail(IPC_ERR_HIP, "cell kernel launch failed: %s", hipGetErrorString(e));
@@ -1658,7 +1665,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
         HIPCHK(hipEventRecord(h->ev_join_own, st0));
         HIPCHK(hipStreamWaitEvent(st, h->ev_join_own, 0));
     }
-    for (int k = 0; k < h->n_side; ++k) {
+    for (int k = 0; k < n_side; ++k) {
         HIPCHK(hipEventRecord(h->ev_join[k], h->side[k]));
         HIPCHK(hipStreamWaitEvent(st, h->ev_join[k], 0));
     }
