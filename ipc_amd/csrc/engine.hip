@@ -361,17 +361,19 @@ __global__ __launch_bounds__(256) void k_assemble(int N, int words, const int* s
     }
 }
 
-// Greedy set-max: candidates in processing order, 32 per round (two per wave: the rows of both are requested together,
+// Greedy set-max: candidates in processing order, 64 per round (four per wave -- 32 / two until round 5: a round is two
+// trips to memory whatever it holds, and at N = 25 000 the 160 rounds were 1.3 ms that no rank of an 8-GPU run can shed;
+// the rows of a wave's candidates are requested together,
 // a round is a memory round trip).  Candidates whose own cell failed can never join, so the order list is first
 // compacted to those with a set diagonal bit (order preserved).  Within a round the candidates are taken in order: one
 // joins if its row covers the set as it stood before the round AND every member of the round taken before it.
 __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* order,
                                                   const unsigned long long* bits, unsigned char* accepted, int* live)
 {
-    constexpr int CPW = 2, RC = 16 * CPW;           // candidates per wave / per round
+    constexpr int CPW = 4, RC = 16 * CPW;           // candidates per wave / per round
     extern __shared__ unsigned long long acc[];     // [words] accepted mask
     __shared__ int okflag[RC];
-    __shared__ unsigned conf[RC];
+    __shared__ unsigned long long conf[RC];
     __shared__ int kk[RC];
     __shared__ int wcount[16];
     __shared__ int nlive_s;
@@ -429,15 +431,15 @@ __global__ __launch_bounds__(1024) void k_set_max(int N, int words, const int* o
                 m = (unsigned)((bits[(size_t)k[c] * words + (o >> 6)] >> (o & 63)) & 1ull);
             }
             const unsigned long long bal = __ballot(m != 0);
-            if (lane == 0) conf[c * 16 + wave] = (unsigned)(bal & 0xffffffffull);
+            if (lane == 0) conf[c * 16 + wave] = bal;
         }
         __syncthreads();
         if (tid == 0) {
-            unsigned taken = 0;
+            unsigned long long taken = 0;
             for (int w = 0; w < RC; ++w) {
                 if (kk[w] < 0 || !okflag[w]) continue;
                 if ((conf[w] & taken) != taken) continue;
-                taken |= 1u << w;
+                taken |= 1ull << w;
                 acc[kk[w] >> 6] |= 1ull << (kk[w] & 63);
                 accepted[kk[w]] = 1;
             }
