@@ -70,17 +70,14 @@ struct BandArgs {
     int bwb;                 // block half-bandwidth of the band loops
     int* abort_seen;         // device word: workgroup 0 publishes what it read from the host's abort word
     const double* zero;      // a word that holds 0.0 (entries outside the profile are read from it)
-    int dbg;                 // IPC_BAND_DBG (experiments): 1 = every thread fences both sides of every barrier, 2 = chain phases on workgroup 0 only
 };
 
 // ---- grid-wide phase helpers --------------------------------------------------------------------------------------
 // Every workgroup arrives once.  fence: the phase in front of the barrier wrote data with plain stores that other
 // workgroups read behind it (release before the arrival, acquire after the last one has arrived; one lane each).
-__shared__ int band_dbg_flags;
 __device__ __forceinline__ bool band_barrier(GridBar& gb, bool fence)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (fence && (band_dbg_flags & 1)) __threadfence();
     __syncthreads();
     if (gb.G == 1) return true;
     gb.target += (unsigned)gb.G;
@@ -100,7 +97,6 @@ __device__ __forceinline__ bool band_barrier(GridBar& gb, bool fence)
         if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    if (fence && (band_dbg_flags & 1)) __threadfence();
     return __hip_atomic_load(gb.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
@@ -294,7 +290,7 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         old[e] = ld_shared(&A[adr]);
     }
     after_loads();
-    prof_add1(prof, kProfBsDots, ts0);
+    prof_add1(prof, kProfTileBlock, ts0);
     unsigned long long tq = prof_now();
     if (has) {
 #pragma unroll
@@ -303,9 +299,9 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
             x[s2] = (c < nbk && pvalid && B.in(prow, k0 + c)) ? x[s2] : 0.0;
         }
         asm volatile("" :: "v"(x[0]), "v"(x[NS - 1]));
-        prof_add1(prof, kProfBsPrefetch, tq); tq = prof_now();
+        prof_add1(prof, kProfTileSelect, tq); tq = prof_now();
         trsm32_lanes<LPR>(x, DT, q);
-        prof_add1(prof, kProfBsSync, tq); tq = prof_now();
+        prof_add1(prof, kProfTileTrsm, tq); tq = prof_now();
         double (*P)[64 + 1] = first ? Ai : Aj;
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) P[s2 * LPR + q][lrow] = (s2 * LPR + q) < nbk ? x[s2] : 0.0;
@@ -318,7 +314,7 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         }
     }
     __syncthreads();
-    prof_add1(prof, kProfBsTri, tq);
+    prof_add1(prof, kProfTileStore, tq);
     prof_add1(prof, kProfHelpSolve, ts0);
     const unsigned long long tu0 = prof_now();
     if (upd) {
@@ -629,8 +625,6 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
 __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* x, PersistCtl* ctl, int* info)
 {
     extern __shared__ double lds[];
-    if (threadIdx.x == 0) band_dbg_flags = 0;
-    __syncthreads();
     GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error, nullptr};
     bool alive = true;
     const int r = bband_factor(Q.A, Q.Lf, Q.dinv, Q.B, gb, lds, alive);
@@ -669,9 +663,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     (void)D0; (void)D1;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
-    if (tid == 0) band_dbg_flags = Q.dbg;
-    __syncthreads();
-    const int Gc = (Q.dbg & 2) ? 1 : G;                       // workgroups that share the chain phases
+    const int Gc = G;                                         // workgroups that share the chain phases (all of them)
     GridBar gb{&P.ctl->bar, 0u, G, &P.ctl->error, P.prof};
     const int L = D0.L, nl = D0.nl, ld = D0.ld;
     constexpr int d = T::kD;
@@ -697,8 +689,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         // no block covers (a column's last kD - 1 - c band rows, and the padding up to W) are zero and stay zero
         const int nlb = Q.nlb, bw1 = Q.bwb + 1;
         const long nband = (long)nlb * bw1, nwide = (long)(nl - nlb) * nl;
-        const int Ga = (Q.dbg & 4) ? 1 : G;
-        if (g >= Ga) return;
+        const int Ga = G;
         for (long q = (long)g * kPT + tid; q < nband + nwide; q += (long)Ga * kPT) {
             int l1, l2;
             if (q < nband) { l1 = (int)(q / bw1); l2 = l1 - (int)(q - (long)l1 * bw1); }
@@ -720,7 +711,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         { const Dev Dv = view(vsel); alive = band_scan(Dv.ps, T::kNPS, L, ld, lds, Q.gscan, gb, Gc) && alive; }
         prof_add(P.prof, kProfPre, t0); t0 = prof_now();
         { const Dev Dv = view(vsel); assemble(Dv); }
-        alive = band_barrier(gb, (Q.dbg & 8) != 0) && alive;
+        alive = band_barrier(gb, false) && alive;
         prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
         if (alive) info = bband_factor(Q.A, Q.Lf, Q.dinv, B, gb, lds, alive);

@@ -74,7 +74,9 @@ struct GridBar { unsigned* ctr; unsigned target; int G; int* error; unsigned lon
 // phase clocks (thread 0 of workgroup 0 only; prof == nullptr: off)
 enum { kProfTotal = 0, kProfPre, kProfHandoff, kProfAssemble, kProfFactor, kProfFactorWork, kProfFactorWait, kProfBacksolve,
        kProfPost, kProfTrial, kProfRest, kProfIterations, kProfSteps,
-       kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfBsDots, kProfBsPrefetch, kProfBsSync, kProfBsTri, kProfN };
+       kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfBsDots, kProfBsPrefetch, kProfBsSync, kProfBsTri,
+       kProfTileBlock, kProfTileSelect, kProfTileTrsm, kProfTileStore,      // band kernel, first tile workgroup: until the column's block has arrived / operands selected / panel solve / stores drained
+       kProfN };
 __device__ __forceinline__ unsigned long long prof_now() { return wall_clock64(); }
 __device__ __forceinline__ void prof_add(unsigned long long* prof, int slot, unsigned long long t0)
 {
@@ -1143,7 +1145,7 @@ public:
             if (getenv("IPC_BAND_DEBUG"))
                 fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d\n", L, nl, plan.nlb, plan.bwb,
                         n, band_.W, band_.m, G);
-            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8), getenv("IPC_BAND_DBG") ? atoi(getenv("IPC_BAND_DBG")) : 0};
+            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8)};
             hipLaunchKernelGGL(cluster_band_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P, Q);
         } else {
             G = std::max(1, std::min(G, resident_limit));

@@ -1031,7 +1031,8 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         hipMemcpy(p, h->d_prof, sizeof(p), hipMemcpyDeviceToHost);
         static const char* names[kProfN] = {"total", "pre", "handoff", "assemble", "factor", "factor_work", "factor_wait", "backsolve",
                                             "post", "trial", "rest", "iterations", "steps", "help_dt", "help_solve", "help_update", "help_wait",
-                                            "look_load", "look_solve", "look_fill", "look_potrf", "look_publish", "bs_dots", "bs_prefetch", "bs_sync", "bs_triangle"};
+                                            "look_load", "look_solve", "look_fill", "look_potrf", "look_publish", "bs_dots", "bs_prefetch", "bs_sync", "bs_triangle",
+                                            "tile_block", "tile_select", "tile_trsm", "tile_store"};
         fprintf(stderr, "{\"persist_profile_us\": {");
         for (int k = 0; k < kProfN; ++k)
             fprintf(stderr, "%s\"%s\": %.1f", k ? ", " : "", names[k], (k == kProfIterations || k == kProfSteps) ? (double)p[k] : p[k] * 0.01);
@@ -3017,7 +3018,7 @@ extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, 
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bband_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * kLdsTotal)));
     HIPCHK(hipMemset(ddinv + B.n + 32, 0, sizeof(double)));                 // (the word that holds 0.0)
-    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, ddinv + B.n + 32, 0};
+    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, ddinv + B.n + 32};
     hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
