@@ -638,14 +638,16 @@ __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* 
 // Band assembly of pose type T: block (l1, l2) of the capacitance system into the banded layout (unknown index of loop l,
 // component r: kD * l + r -- the loops are already in band order)
 template <class T>
-__device__ __forceinline__ void band_assemble_block(const typename T::Dev& Dv, const BandArgs& Q, int l1, int l2)
+__device__ __forceinline__ void band_assemble_block(const typename T::Dev& Dv, const BandArgs& Q, int l1, int l2, int r)
 {
     double* A = Q.A;
     const BandLayout B = Q.B;
     // (a diagonal block comes as a full d x d block; the banded layout holds the lower triangle only -- an entry above
     // the diagonal would land in the previous column's dense rows)
-    T::assemble_core(Dv, l1, l2, [&](int row, int col, double v) { if (row >= col) st_shared(&A[B.at(row, col)], v); },
-                     [&](int col, double v) { st_shared(&A[B.at(B.n, col)], v); });
+    // PLAIN stores, published by the fenced barrier behind the assembly: 8-byte write-through (sc1) stores are one fabric
+    // write each, and at 36 per block pair the assembly was bound by them (266 us per iteration at 11 000 pairs)
+    T::assemble_row(Dv, l1, l2, r, [&](int row, int col, double v) { if (row >= col) gptr(A)[B.at32(row, col)] = v; },
+                    [&](int col, double v) { gptr(A)[B.at32(B.n, col)] = v; });
 }
 
 template <class T>
@@ -690,16 +692,19 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         const int nlb = Q.nlb, bw1 = Q.bwb + 1;
         const long nband = (long)nlb * bw1, nwide = (long)(nl - nlb) * nl;
         const int Ga = G;
-        for (long q = (long)g * kPT + tid; q < nband + nwide; q += (long)Ga * kPT) {
+        constexpr int AR = T::kAsmRows;                       // units of work per block pair (SE3: one per block row)
+        for (long u = (long)g * kPT + tid; u < (nband + nwide) * AR; u += (long)Ga * kPT) {
+            const long q = u / AR;
+            const int r = (int)(u - q * AR);
             int l1, l2;
             if (q < nband) { l1 = (int)(q / bw1); l2 = l1 - (int)(q - (long)l1 * bw1); }
             else { const long w = q - nband; l1 = nlb + (int)(w / nl); l2 = (int)(w - (long)(l1 - nlb) * nl); }
-            if (l2 >= 0 && l2 <= l1) band_assemble_block<T>(Dv, Q, l1, l2);
+            if (l2 >= 0 && l2 <= l1) band_assemble_block<T>(Dv, Q, l1, l2, r);
         }
         const int covered = d * bw1;
         for (int j = g * kPT + tid; j < B.nb; j += Ga * kPT) {
             const int c = j % d;
-            for (int o = covered - c; o < B.W; ++o) st_shared(&Q.A[(size_t)j * B.ldb + o], 0.0);
+            for (int o = covered - c; o < B.W; ++o) gptr(Q.A)[(size_t)j * B.ldb + o] = 0.0;
         }
     };
     auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         { const Dev Dv = view(vsel); alive = band_scan(Dv.ps, T::kNPS, L, ld, lds, Q.gscan, gb, Gc) && alive; }
         prof_add(P.prof, kProfPre, t0); t0 = prof_now();
         { const Dev Dv = view(vsel); assemble(Dv); }
-        alive = band_barrier(gb, false) && alive;
+        alive = band_barrier(gb, true) && alive;             // (release / acquire: the system was written with plain stores)
         prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
         if (alive) info = bband_factor(Q.A, Q.Lf, Q.dinv, B, gb, lds, alive);

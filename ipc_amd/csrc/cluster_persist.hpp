@@ -733,6 +733,10 @@ struct PersistSe2 {
     __device__ static void assemble(const Dev& D, int l1, int l2) { gk_assemble_at(D, l1, l2); }
     template <class Put, class PutRhs>
     __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk_assemble_core(D, l1, l2, put, put_rhs); }
+    // the banded kernel's unit of assembly work: the whole 3 x 3 block
+    static constexpr int kAsmRows = 1;
+    template <class Put, class PutRhs>
+    __device__ static void assemble_row(const Dev& D, int l1, int l2, int, Put put, PutRhs put_rhs) { gk_assemble_core(D, l1, l2, put, put_rhs); }
     __device__ static void nu(const Dev& D, int l) { gk_nu_at(D, l); }
     __device__ static void events(const Dev& D, int j) { gk_events_at(D, j); }
     __device__ static void rho(const Dev& D, int i) { gk_rho_at(D, i); }
@@ -783,6 +787,10 @@ struct PersistSe3 {
     __device__ static void assemble(const Dev& D, int l1, int l2) { gk3_assemble_at(D, l1, l2); }
     template <class Put, class PutRhs>
     __device__ static void assemble_core(const Dev& D, int l1, int l2, Put put, PutRhs put_rhs) { gk3_assemble_core(D, l1, l2, put, put_rhs); }
+    // the banded kernel's unit of assembly work: one row of a 6 x 6 block
+    static constexpr int kAsmRows = 6;
+    template <class Put, class PutRhs>
+    __device__ static void assemble_row(const Dev& D, int l1, int l2, int r, Put put, PutRhs put_rhs) { gk3_assemble_row(D, l1, l2, r, put, put_rhs); }
     __device__ static void nu(const Dev& D, int l) { gk3_nu_at(D, l); }
     __device__ static void events(const Dev& D, int j) { gk3_events_at(D, j); }
     __device__ static void rho(const Dev& D, int i) { gk3_rho_at(D, i); }

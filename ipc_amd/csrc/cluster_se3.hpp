@@ -342,6 +342,55 @@ __device__ __forceinline__ void gk3_assemble_core(const ClusterDev3& D, int l1, 
         }
     }
 }
+// One ROW r of the same block (the banded kernel gives every block row a thread of its own: six times the threads, and the
+// operands of a row -- Gamma_l2 whole, row r of Gamma_l1, the prefix-sum differences -- are requested together, two trips
+// to L2 per row instead of seven per row in the rolled form above, whose threads each walked through a dozen block pairs:
+// 17 % of an iteration).  The arithmetic and its order are gk3_assemble_core's: same bits.
+template <class Put, class PutRhs>
+__device__ __forceinline__ void gk3_assemble_row(const ClusterDev3& D, int l1, int l2, int r, Put put, PutRhs put_rhs)
+{
+    if (l2 >= D.nl || l1 >= D.nl || l2 > l1) return;
+    const int lo1 = min(D.lfrom[l1], D.lto[l1]), hi1 = max(D.lfrom[l1], D.lto[l1]);
+    const int lo2 = min(D.lfrom[l2], D.lto[l2]), hi2 = max(D.lfrom[l2], D.lto[l2]);
+    const int a = max(lo1, lo2), bq = min(hi1, hi2);
+    const bool ov = bq > a, diag = l1 == l2;
+    const int ia = ov ? a : 0, ib = ov ? bq : 0;             // (index 0 of every row is a valid slot: no predicated loads)
+    double Pa[21], Pb[21], g1[6], G2[36];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { Pb[k] = D.ps[(size_t)k * D.ld + ib]; Pa[k] = D.ps[(size_t)k * D.ld + ia]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) g1[q] = D.gam[(size_t)(6 * r + q) * D.nl + l1];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) G2[k] = D.gam[(size_t)k * D.nl + l2];
+    __builtin_amdgcn_sched_barrier(0);
+    double Mm[21], T[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Mm[k] = ov ? Pb[k] - Pa[k] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) acc += g1[p] * Mm[sym6_idx(p, q)];
+        T[q] = acc;
+    }
+    double sgl[21];
+    if (diag) gk3_sym(D.cand, D.cstride, G_SG, D.lcand[l1], sgl);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc += T[q] * G2[6 * c + q];
+        if (diag) acc += sgl[sym6_idx(r, c)];
+        put(6 * l1 + r, 6 * l2 + c, acc);
+    }
+    if (diag) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            acc += g1[q] * (D.ps[(size_t)(21 + q) * D.ld + hi1] - D.ps[(size_t)(21 + q) * D.ld + lo1]);
+        put_rhs(6 * l1 + r, D.le[(size_t)r * D.nl + l1] - acc);
+    }
+}
 __device__ __forceinline__ void gk3_assemble_at(const ClusterDev3& D, int l1, int l2)
 {
     const int NS = 6 * D.nl;

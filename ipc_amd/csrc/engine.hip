@@ -2135,7 +2135,7 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>
         auto lo_of = [&](int q) { return q == (int)n ? h->h_lo[k] : h->h_lo[cns[q]]; };
         auto hi_of = [&](int q) { return q == (int)n ? h->h_hi[k] : h->h_hi[cns[q]]; };
         std::sort(idx.begin(), idx.end(), [&](int x, int y) { return lo_of(x) != lo_of(y) ? lo_of(x) < lo_of(y) : x < y; });
-        size_t start = 0, pos_k = 0;
+        size_t start = 0;
         int reach = hi_of(idx[0]);
         bool has_k = idx[0] == (int)n;
         size_t cs = 0, ce = n + 1;
@@ -2149,7 +2149,6 @@ static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>
                 has_k = has_k || idx[p] == (int)n;
             }
         }
-        (void)pos_k;
         for (size_t p = cs; p < ce; ++p) {
             if (idx[p] == (int)n) continue;
             const int e = cns[idx[p]];
