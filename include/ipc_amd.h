@@ -185,7 +185,12 @@ int ipc_run_set_only(ipc_engine_t* h, uint8_t* accepted_out, int* solved_cells_o
  * more than one GPU; a multi-process run gathers with RCCL instead, ipc_amd/dist.py).  engines[r], r < n_engines, were
  * created on different devices with the same chain and given the same candidate list; engines[r] acts as rank r of
  * world n_engines: all solve their rows concurrently, the shards are gathered onto engines[0]'s device by peer copies
- * over xGMI, which assembles the matrix and runs the set-max.  Outputs as ipc_run. */
+ * over xGMI, which assembles the matrix and runs the set-max.  Outputs as ipc_run.
+ * Peer access: the shards move with hipMemcpyPeerAsync, which works whether or not the devices have peer access to each
+ * other -- with access (hipDeviceEnablePeerAccess, the CALLER's decision: it is a process-wide setting the library does not
+ * touch) the copy goes GPU to GPU over xGMI; without it, or where the platform denies it (IOMMU / container restrictions:
+ * hipDeviceCanAccessPeer = 0), the runtime stages the copy through host memory: the same bytes arrive, at PCIe speed
+ * (78 MB for C5: ~5 ms instead of < 1 ms).  Engines that share a device (tests) copy device to device. */
 int ipc_run_sharded(ipc_engine_t** engines, int n_engines, uint64_t* bits_out, uint8_t* accepted_out);
 
 /* Diagnostics of the last ipc_solve_rows(): number of solved cells, and their records. */
