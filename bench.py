@@ -84,6 +84,10 @@ def build_workload(name):
         g = synth.inject_outliers(g0, 3000, seed=41, local=True)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=g0.N)
         desc = "SE2 synthetic (V=4000, %d true loops of span <= 140) + 3000 injected local outliers" % g0.N
+    elif name == "R2k":       # SE2 spiral, every pose closed onto the turn before: one growing cluster of ~2 000 loops (banded solver on 3 x 3 blocks)
+        g = synth.inject_outliers(synth.ring_se2(), 300, seed=23)
+        cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=1950)
+        desc = "SE2 spiral synthetic (V=2000, 1950 true loops of span 50) + 300 injected outliers"
     elif name == "tiny":
         g = synth.inject_outliers(synth._se2_graph(300, 24, seed=5, laps=3.0), 40, seed=4)
         cfg = Config(6.251, 50, 11.345, 100, 10.0, canonic_inliers=24)

@@ -351,7 +351,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
     auto publish = [&](int kb0, int nbb) {
         for (int idx = tid; idx < kCB * kCB; idx += kPT) {
             const int r = idx % kCB, c = idx / kCB;
-            if (r < nbb && c < nbb && r >= c) st_shared(&Lf[B.at(kb0 + r, kb0 + c)], Dn[r][c]);
+            if (r < nbb && c < nbb && r >= c) st_shared(&Lf[B.at32(kb0 + r, kb0 + c)], Dn[r][c]);
         }
         if (tid < nbb) st_shared(&dinv[kb0 + tid], Dninv[tid]);
     };
@@ -359,7 +359,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
         const int nb0 = min(kCB, n);
         for (int idx = tid; idx < kCB * kCB; idx += kPT) {
             const int r = idx % kCB, c = idx / kCB;
-            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[B.at(r, c)]) : (r == c ? 1.0 : 0.0);
+            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[B.at32(r, c)]) : (r == c ? 1.0 : 0.0);
         }
         __syncthreads();
         bool ok = true;
@@ -382,7 +382,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
             for (int qd = 0; qd < kDtPass; ++qd) {
                 const int idx = tid + qd * kPT, c = idx >> 5, r = idx & 31;
                 const bool in = r < nbk && c < nbk && r >= c;
-                dtv[qd] = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[B.at(k0 + r, k0 + c)]) : &dinv[k0]);
+                dtv[qd] = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[B.at32(k0 + r, k0 + c)]) : &dinv[k0]);
             }
         }
         auto write_dt = [&]() {
@@ -424,7 +424,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                 __syncthreads();
                 for (int idx = tid; idx < kCB * kCB; idx += kPT) {
                     const int r = idx % kCB, c = idx / kCB;
-                    Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[B.at(k1 + r, k1 + c)]) : (r == c ? 1.0 : 0.0);
+                    Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[B.at32(k1 + r, k1 + c)]) : (r == c ? 1.0 : 0.0);
                 }
             } else {
                 // rows k1 .. k1+nb2 of block column k0 against the block, then the update of the next diagonal block with
@@ -442,7 +442,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                     if ((r + 1) * (r + 2) / 2 <= idx) ++r;
                     er[q] = r; es[q] = idx - r * (r + 1) / 2;
                     const bool in = idx < kTri && r < nb2;
-                    oldv[q] = ld_shared(&A[in ? B.at(k1 + r, k1 + es[q]) : (size_t)0]);
+                    oldv[q] = ld_shared(&A[in ? B.at32(k1 + r, k1 + es[q]) : 0u]);
                 }
                 if (tid < 128) {
                     constexpr int LPR = 4, NS = kCB / LPR;
@@ -452,7 +452,7 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) {
                         const int c = s2 * LPR + q;
-                        x[s2] = ld_shared(&A[(c < nbk && pvalid) ? B.at(prow, k0 + c) : (size_t)0]);
+                        x[s2] = ld_shared(&A[(c < nbk && pvalid) ? B.at32(prow, k0 + c) : 0u]);
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) x[s2] = ((s2 * LPR + q) < nbk && pvalid) ? x[s2] : 0.0;

@@ -255,7 +255,7 @@ __device__ __forceinline__ void publish_block(double (*Dn)[kCB + 1], const doubl
 {
     for (int idx = threadIdx.x; idx < kCB * kCB; idx += kPT) {
         const int r = idx % kCB, c = idx / kCB;
-        if (r < nbb && c < nbb && r >= c) st_shared(&Lf[(size_t)(kb0 + c) * ld + kb0 + r], Dn[r][c]);
+        if (r < nbb && c < nbb && r >= c) st_shared(&Lf[(unsigned)(kb0 + c) * (unsigned)ld + (unsigned)(kb0 + r)], Dn[r][c]);
     }
     if (threadIdx.x < nbb) st_shared(&dinv[kb0 + threadIdx.x], Dninv[threadIdx.x]);
 }
@@ -392,7 +392,7 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
         const int c = s2 * LPR + q;
-        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (unsigned)(k0 + c) * (unsigned)ld + (unsigned)prow : 0u]);      // (32-bit: a system holds < 2^32 doubles)
     }
     after_loads();
     if (has) {
@@ -406,7 +406,7 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
         if (first && by == 0 && pvalid) {
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
-                if (s2 * LPR + q < nb) st_shared(&Lf[(size_t)(k0 + s2 * LPR + q) * ld + prow], x[s2]);
+                if (s2 * LPR + q < nb) st_shared(&Lf[(unsigned)(k0 + s2 * LPR + q) * (unsigned)ld + (unsigned)prow], x[s2]);
         }
     }
     __syncthreads();
@@ -421,7 +421,7 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + own.i_of(e), j = j0 + own.j_of(e);
             const bool in = j < n && i <= n && i >= j;
-            old[e] = ld_shared(&A[in ? (size_t)j * ld + i : (size_t)0]);         // (always a valid address: no branch per element)
+            old[e] = ld_shared(&A[in ? (unsigned)j * (unsigned)ld + (unsigned)i : 0u]);         // (always a valid address: no branch per element)
         }
         double acc[16];
         tile_product(Ai, Aj, own, acc);
@@ -431,7 +431,7 @@ __device__ __forceinline__ void chol_tile(double* A, double* Lf, int n, int ld, 
             if (j >= n) continue;
             // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
             if (skip_next_diag && i < min(k1 + kCB, n)) continue;       // (row n is the right-hand side, never part of it)
-            if (i <= n && i >= j) st_shared(&A[(size_t)j * ld + i], old[e] - acc[e]);
+            if (i <= n && i >= j) st_shared(&A[(unsigned)j * (unsigned)ld + (unsigned)i], old[e] - acc[e]);
         }
     }
     __syncthreads();
@@ -460,7 +460,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
         const int nb0 = min(kCB, n);
         for (int idx = tid; idx < kCB * kCB; idx += kPT) {
             const int r = idx % kCB, c = idx / kCB;
-            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[(size_t)c * ld + r]) : (r == c ? 1.0 : 0.0);
+            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[(unsigned)c * (unsigned)ld + (unsigned)r]) : (r == c ? 1.0 : 0.0);
         }
         __syncthreads();
         bool ok = true;
@@ -482,7 +482,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
             for (int qd = 0; qd < kDtPass; ++qd) {
                 const int idx = tid + qd * kPT, c = idx >> 5, r = idx & 31;
                 const bool in = r < nb && c < nb;
-                dtv[qd] = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[(size_t)(k0 + c) * ld + k0 + r]) : &dinv[k0]);
+                dtv[qd] = ld_shared(in ? (r == c ? &dinv[k0 + c] : &Lf[(unsigned)(k0 + c) * (unsigned)ld + (unsigned)(k0 + r)]) : &dinv[k0]);
             }
         }
         auto write_dt = [&]() {
@@ -523,7 +523,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                 __syncthreads();
                 for (int idx = tid; idx < kCB * kCB; idx += kPT) {
                     const int r = idx % kCB, c = idx / kCB;
-                    Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[(size_t)(k1 + c) * ld + k1 + r]) : (r == c ? 1.0 : 0.0);
+                    Dn[r][c] = (r < nb2 && c < nb2 && r >= c) ? ld_shared(&A[(unsigned)(k1 + c) * (unsigned)ld + (unsigned)(k1 + r)]) : (r == c ? 1.0 : 0.0);
                 }
             } else {
                 // One step ahead of the helpers: rows k1 .. k1+nb2 of block column k0 against the block, then the
@@ -541,7 +541,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
                     if ((r + 1) * (r + 2) / 2 <= idx) ++r;
                     er[q] = r; es[q] = idx - r * (r + 1) / 2;
                     const bool in = idx < kTri && r < nb2;                                      // (sc <= r < nb2)
-                    oldv[q] = ld_shared(&A[in ? (size_t)(k1 + es[q]) * ld + k1 + r : (size_t)0]);
+                    oldv[q] = ld_shared(&A[in ? (unsigned)(k1 + es[q]) * (unsigned)ld + (unsigned)(k1 + r) : 0u]);
                 }
                 if (tid < 128) {
                     constexpr int LPR = 4, NS = kCB / LPR;
@@ -551,7 +551,7 @@ __device__ __noinline__ int pchol_factor(double* A, double* Lf, double* dinv, in
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) {
                         const int c = s2 * LPR + q;
-                        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (size_t)(k0 + c) * ld + prow : (size_t)0]);
+                        x[s2] = ld_shared(&A[(c < nb && pvalid) ? (unsigned)(k0 + c) * (unsigned)ld + (unsigned)prow : 0u]);
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) x[s2] = ((s2 * LPR + q) < nb && pvalid) ? x[s2] : 0.0;
@@ -632,9 +632,9 @@ __device__ __noinline__ void pchol_backsolve(const double* Lf, int n, double* x,
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int idx = tid + q * kPT, r = idx % kCB, c = idx / kCB;
-            dpre[q] = ld_shared(&Lf[(idx < kCB * kCB && r < nb && c < nb && r >= c) ? (size_t)(k0 + c) * ld + k0 + r : (size_t)0]);
+            dpre[q] = ld_shared(&Lf[(idx < kCB * kCB && r < nb && c < nb && r >= c) ? (unsigned)(k0 + c) * (unsigned)ld + (unsigned)(k0 + r) : 0u]);
         }
-        ypre = ld_shared(&Lf[l < nb ? (size_t)(k0 + l) * ld + n : (size_t)0]);
+        ypre = ld_shared(&Lf[l < nb ? (unsigned)(k0 + l) * (unsigned)ld + (unsigned)n : 0u]);
     };
     prefetch(nblk - 1);
     for (int kb = nblk - 1; kb >= 0; --kb) {

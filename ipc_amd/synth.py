@@ -163,6 +163,52 @@ def _se2_graph(V, n_loops, seed, laps, sig_o=(0.03, 0.012), sig_l=(0.05, 0.02), 
                      dict(name=name, seed=seed, canonic_inliers=n_loops, ground_truth=gt))
 
 
+def ring_se2(seed=20261003, V=2000, per_ring=50, radius=8.0, sig_o=(0.03, 0.012), sig_l=(0.05, 0.02), odom_trust=10.0):
+    """The SE2 counterpart of sphere_like(): a slowly widening spiral with `per_ring` poses per turn, true loops join pose i
+    with the pose one turn later (i + per_ring) -- V - per_ring loops of equal span that chain into ONE cluster in the
+    faithful mode (round 5: the banded large-cluster solver on 3 x 3 blocks)."""
+    rng = np.random.default_rng(seed)
+    k = np.arange(V)
+    ang = 2 * np.pi * k / per_ring
+    rad = radius * (1.0 + 0.15 * k / V)
+    gx, gy = rad * np.cos(ang), rad * np.sin(ang)
+    gth = _wrap(ang + np.pi / 2)
+    gt = np.stack([gx, gy, gth], axis=1)
+    th0 = gt[0, 2]
+    gt[:, :2] -= gt[0, :2]
+    c0, s0 = math.cos(-th0), math.sin(-th0)
+    xy = gt[:, :2].copy()
+    gt[:, 0] = c0 * xy[:, 0] - s0 * xy[:, 1]
+    gt[:, 1] = s0 * xy[:, 0] + c0 * xy[:, 1]
+    gt[:, 2] = _wrap(gt[:, 2] - th0)
+    odom_meas = np.zeros((V - 1, 3))
+    odom_info = np.zeros((V - 1, 6))
+    for j in range(V - 1):
+        cov, inf = _se2_info(rng, sig_o[0], sig_o[1])
+        z = _se2_between(gt[j], gt[j + 1]) + rng.multivariate_normal(np.zeros(3), cov / odom_trust)
+        z[2] = _wrap(z[2])
+        odom_meas[j] = z
+        odom_info[j] = _upper(inf)
+    n_loops = V - per_ring
+    loop_ids = np.stack([np.arange(n_loops), np.arange(n_loops) + per_ring], axis=1).astype(np.int32)
+    loop_meas = np.zeros((n_loops, 3))
+    loop_info = np.zeros((n_loops, 6))
+    for q, (a, b) in enumerate(loop_ids):
+        cov, inf = _se2_info(rng, sig_l[0], sig_l[1])
+        z = _se2_between(gt[a], gt[b]) + rng.multivariate_normal(np.zeros(3), cov)
+        z[2] = _wrap(z[2])
+        loop_meas[q] = z
+        loop_info[q] = _upper(inf)
+    verts = np.zeros((V, 3))
+    for j in range(V - 1):
+        a = verts[j]
+        c, s_ = math.cos(a[2]), math.sin(a[2])
+        z = odom_meas[j]
+        verts[j + 1] = [a[0] + c * z[0] - s_ * z[1], a[1] + s_ * z[0] + c * z[1], _wrap(a[2] + z[2])]
+    return PoseGraph(2, verts, odom_meas, odom_info, loop_ids, loop_meas, loop_info,
+                     dict(name="ring-se2", seed=seed, canonic_inliers=n_loops, ground_truth=gt))
+
+
 def intel_like(seed=20260929, V=1228, n_loops=256):
     return _se2_graph(V, n_loops, seed, laps=6.0, name="INTEL-like")
 

@@ -14,6 +14,8 @@ The CPU oracle (oracle/ipc_oracle.c, test infrastructure) runs the whole candida
   c4  bench.py workload C4 (BASELINE configs[3]: sphere2500-like SE3, all 2 450 true loops + 2 000 outliers) -- a PREFIX:
       the candidates the oracle finishes within --seconds (round 5; clusters of > 1 000 loops, the banded capacitance solve)
   c5  bench.py workload C5 (BASELINE configs[4]: V=50 000 SE3 chain, 5 000 true loops + 20 000 local outliers) -- a PREFIX
+  r2k bench.py workload R2k (SE2 spiral, V=2 000, 1 950 true loops of span 50 + 300 outliers) -- a PREFIX: the SE2
+      instance of the banded large-cluster solver (one growing cluster, 3 x 3 blocks)
 
 and records per candidate (in processing order): decision, cluster span lo/hi, cluster size,
 max edge chi2.  The workloads themselves are regenerated from their seeds by ipc_amd.synth (the
@@ -33,7 +35,7 @@ import numpy as np
 
 from oracle import oracle as O
 
-WORKLOAD = {"c1": "C1", "c2": "C2", "se3": "C4s", "c4m": "C4m", "c3": "C3", "c4": "C4", "c5": "C5"}
+WORKLOAD = {"c1": "C1", "c2": "C2", "se3": "C4s", "c4m": "C4m", "c3": "C3", "c4": "C4", "c5": "C5", "r2k": "R2k"}
 
 
 def run(tag, seconds=None):
