@@ -1152,7 +1152,8 @@ public:
             const int want = std::max((tiles + kPSG - 1) / kPSG, std::min(24, (L + nl) / (4 * kPT)));
             G = 1 + std::min(max_helpers, want);
             G = std::max(1, std::min(G, resident_limit));
-            if (getenv("IPC_BAND_DEBUG"))
+            static const bool band_debug = getenv("IPC_BAND_DEBUG") != nullptr;
+            if (band_debug)
                 fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d\n", L, nl, plan.nlb, plan.bwb,
                         n, band_.W, band_.m, G);
             BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8)};
@@ -1250,6 +1251,7 @@ private:
             IPC_CL_CHK(hipMalloc(&d_ctl_, sizeof(PersistCtl)));
             IPC_CL_CHK(hipMalloc(&d_abort_seen_, sizeof(int) * 16));       // [0]: abort word as workgroup 0 saw it; [8..9]: a double 0.0
             IPC_CL_CHK(hipMemset(d_abort_seen_, 0, sizeof(int) * 16));
+            IPC_CL_CHK(hipStreamSynchronize(nullptr));             // (NULL-stream memsets are not ordered against the non-blocking streams the solves run on)
             for (int k = 0; k < kTabSlots; ++k) IPC_CL_CHK(hipEventCreateWithFlags(&ev_tab_[k], hipEventDisableTiming));
         }
         if (L > capL_ || nl > capNl_) {

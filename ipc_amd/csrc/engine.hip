@@ -1489,9 +1489,8 @@ __global__ void k_scatter_literal(int ncells, const unsigned* slot_off, int nslo
     const int c = lit_idx[t];
     chi[c] = lit_chi[t]; chitot[c] = lit_chitot[t]; meta[c] = lit_meta[t];
 }
-static int resolve_failed_cells(ipc_engine* h, hipStream_t st, int n)
+static int resolve_failed_cells(ipc_engine* h, int n)
 {
-    (void)st;
     h->last_lm_cells = 0;
     if (n == 0) return IPC_OK;
     n = std::min(n, h->failed_cap);
@@ -1723,7 +1722,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
             h->last_literal_cells = n_lit;
         }
         if (h->h_recount[NS]) {
-            if (int rc = resolve_failed_cells(h, st, h->h_recount[NS])) return rc;
+            if (int rc = resolve_failed_cells(h, h->h_recount[NS])) return rc;
         }
     }
     if (total)
