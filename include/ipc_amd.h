@@ -277,6 +277,11 @@ int ipc_debug_dense_solve(int n, const double* system, int mode, int workgroups,
 int ipc_debug_band_solve(int nb, int m, int W, const double* system, int workgroups, double* x_out, int* info_out);
 /* The band structure found for a set of loops (host code, no GPU): a / b = first / last vertex per loop, d = 3 (SE2) or
  * 6 (SE3) unknowns per loop, min_n = smallest system that is banded at all (0: always).  use_out 0: dense solver. */
+/* computeIndependentSubgraph (src/consensus.cpp:124-171) on bare intervals (host code, no GPU): the accepted edges -- positions
+ * into lo / hi -- a candidate [klo, khi] absorbs, and the hull.  sweep 0: the reference's fixed-point re-scan; sweep 1: one pass
+ * over the intervals sorted by first vertex (what the engine uses for sets of 512 and more).  Same set, same hull. */
+int ipc_debug_absorbed_edges(int klo, int khi, int n, const int* lo, const int* hi, int sweep, int* members_out, int* n_members_out,
+                             int* lo_out, int* hi_out);
 int ipc_debug_band_plan(int d, int nl, const int* a, const int* b, int min_n, int* use_out, int* nlb_out, int* bwb_out,
                         int* order_out);
 

@@ -2116,57 +2116,79 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
 // then the threshold / iteration base of :50-52 and the x5 rule of consensus_utils.cpp:12-13.  members = the absorbed
 // edges in the order they were found, then k (:56).
 struct ClusterSpec { int lo, hi, nclu, iters; double th; std::vector<int> members; };
+// The accepted edges (positions into lo / hi, the intervals of the consensus set in acceptance order) that
+// computeIndependentSubgraph (src/consensus.cpp:124-171) absorbs for a candidate [klo, khi], and the hull they reach.
+//   sweep = false: the reference's fixed point, literally -- re-scan the set until nothing new overlaps the growing hull with
+//                  positive length (:140-168); members in the order they are found;
+//   sweep = true : the same SET by one pass over the intervals sorted by first vertex.  The fixed point is the connected
+//                  component of the candidate in the graph "intervals that overlap with positive length" (an edge overlaps the
+//                  hull of a connected set iff it overlaps one of its members: the hull of a connected set has no gaps), and
+//                  the re-scans cost one pass per step the hull grows (C5: 130 passes over 5 000 loops per check); members by
+//                  first vertex.  tests/test_host_logic.py holds the two against each other on random interval sets.
+static void absorbed_edges(int klo, int khi, int n, const int* lo, const int* hi, bool sweep, std::vector<int>& members, int& out_lo, int& out_hi)
+{
+    members.clear();
+    out_lo = klo; out_hi = khi;
+    if (sweep) {
+        std::vector<int> idx(n + 1);
+        for (int q = 0; q <= n; ++q) idx[q] = q;                             // (n = the candidate)
+        auto lo_of = [&](int q) { return q == n ? klo : lo[q]; };
+        auto hi_of = [&](int q) { return q == n ? khi : hi[q]; };
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return lo_of(x) != lo_of(y) ? lo_of(x) < lo_of(y) : x < y; });
+        int start = 0, reach = hi_of(idx[0]), cs = 0, ce = n + 1;
+        bool has_k = idx[0] == n;
+        for (int p = 1; p <= n + 1; ++p) {
+            if (p == n + 1 || lo_of(idx[p]) >= reach) {                       // component [start, p) ends
+                if (has_k) { cs = start; ce = p; break; }
+                if (p == n + 1) break;
+                start = p; reach = hi_of(idx[p]); has_k = idx[p] == n;
+            } else {
+                reach = std::max(reach, hi_of(idx[p]));
+                has_k = has_k || idx[p] == n;
+            }
+        }
+        for (int p = cs; p < ce; ++p) {
+            if (idx[p] == n) continue;
+            out_lo = std::min(out_lo, lo[idx[p]]); out_hi = std::max(out_hi, hi[idx[p]]);
+            members.push_back(idx[p]);
+        }
+        return;
+    }
+    std::vector<char> inc(n, 0);
+    bool found = true;
+    while (found) {
+        found = false;
+        for (int q = 0; q < n; ++q) {
+            if (inc[q]) continue;
+            if (std::min(hi[q], out_hi) - std::max(lo[q], out_lo) <= 0) continue;      // :157-159
+            out_lo = std::min(out_lo, lo[q]); out_hi = std::max(out_hi, hi[q]);
+            inc[q] = 1; found = true;
+            members.push_back(q);
+        }
+    }
+}
+// (host code only: both forms of the cluster search on one interval set; members_out holds positions into lo / hi)
+extern "C" int ipc_debug_absorbed_edges(int klo, int khi, int n, const int* lo, const int* hi, int sweep, int* members_out, int* n_members_out,
+                                        int* lo_out, int* hi_out)
+{
+    if (n < 0 || (n > 0 && (!lo || !hi)) || !n_members_out || !lo_out || !hi_out) return fail(IPC_ERR_ARG, "ipc_debug_absorbed_edges: bad argument");
+    std::vector<int> m;
+    absorbed_edges(klo, khi, n, lo, hi, sweep != 0, m, *lo_out, *hi_out);
+    *n_members_out = (int)m.size();
+    if (members_out) std::copy(m.begin(), m.end(), members_out);
+    return IPC_OK;
+}
 static ClusterSpec cluster_of(const ipc_engine* h, int k, const std::vector<int>& cns)
 {
     ClusterSpec c;
-    c.lo = h->h_lo[k]; c.hi = h->h_hi[k];
-    std::vector<char> inc(cns.size(), 0);
-    bool found = true;
-    if (cns.size() >= 512) {
-        // Large sets (round 5: thousands of accepted loops).  The fixed point below is the connected component of k in
-        // the graph "intervals that overlap with positive length" (an edge overlaps the hull of a connected set iff it
-        // overlaps one of its members), and its re-scans cost one pass per step the hull grows: found here by one sweep over
-        // the intervals sorted by first vertex.  Same member SET; their order is by first vertex instead of by discovery
-        // (sets this large go to the banded solver, which orders its loops itself).
-        const size_t n = cns.size();
-        std::vector<int> idx(n + 1);
-        for (size_t q = 0; q <= n; ++q) idx[q] = (int)q;                   // (n = the candidate)
-        auto lo_of = [&](int q) { return q == (int)n ? h->h_lo[k] : h->h_lo[cns[q]]; };
-        auto hi_of = [&](int q) { return q == (int)n ? h->h_hi[k] : h->h_hi[cns[q]]; };
-        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return lo_of(x) != lo_of(y) ? lo_of(x) < lo_of(y) : x < y; });
-        size_t start = 0;
-        int reach = hi_of(idx[0]);
-        bool has_k = idx[0] == (int)n;
-        size_t cs = 0, ce = n + 1;
-        for (size_t p = 1; p <= n + 1; ++p) {
-            if (p == n + 1 || lo_of(idx[p]) >= reach) {                     // component [start, p) ends
-                if (has_k) { cs = start; ce = p; break; }
-                if (p == n + 1) break;
-                start = p; reach = hi_of(idx[p]); has_k = idx[p] == (int)n;
-            } else {
-                reach = std::max(reach, hi_of(idx[p]));
-                has_k = has_k || idx[p] == (int)n;
-            }
-        }
-        for (size_t p = cs; p < ce; ++p) {
-            if (idx[p] == (int)n) continue;
-            const int e = cns[idx[p]];
-            c.lo = std::min(c.lo, h->h_lo[e]); c.hi = std::max(c.hi, h->h_hi[e]);
-            c.members.push_back(e);
-        }
-        found = false;
-    }
-    while (found) {
-        found = false;
-        for (size_t q = 0; q < cns.size(); ++q) {
-            if (inc[q]) continue;
-            const int e = cns[q];
-            if (std::min(h->h_hi[e], c.hi) - std::max(h->h_lo[e], c.lo) <= 0) continue;
-            c.lo = std::min(c.lo, h->h_lo[e]); c.hi = std::max(c.hi, h->h_hi[e]);
-            inc[q] = 1; found = true;
-            c.members.push_back(e);
-        }
-    }
+    const int n = (int)cns.size();
+    std::vector<int> clo(n), chi(n), pos;
+    for (int q = 0; q < n; ++q) { clo[q] = h->h_lo[cns[q]]; chi[q] = h->h_hi[cns[q]]; }
+    // (sets of 512 and more go through the sweep: their clusters go to the banded solver, which orders its loops itself;
+    // smaller ones keep the discovery order of rounds 1 - 4, i.e. their bits)
+    absorbed_edges(h->h_lo[k], h->h_hi[k], n, clo.data(), chi.data(), n >= 512, pos, c.lo, c.hi);
+    c.members.reserve(pos.size() + 1);
+    for (int q : pos) c.members.push_back(cns[q]);
     if (h->cns_dups) {                         // (an edge accepted twice sits in the set twice, :70, and enters the std::set once)
         std::vector<int> uniq;
         for (int e : c.members) if (std::find(uniq.begin(), uniq.end(), e) == uniq.end()) uniq.push_back(e);
