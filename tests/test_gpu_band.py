@@ -279,3 +279,16 @@ def test_r2k_full_run_against_the_oracle_fixture():
     worst, big, eng = _replay("R2k", "r2k", 1e-6, {})
     assert big >= 1700
     print("\n[R2k] worst relative chi2 difference %.2e, largest cluster %d loops" % (worst, big))
+
+
+def test_c5_pipeline_is_bitwise_the_one_at_a_time_loop():
+    """The same on BASELINE configs[4] (V = 50 000: chain phases spread over every workgroup of a launch, 80 % expected
+    rejects on reduced workgroup counts, cluster search by the sweep once the set holds 512 edges): first 3 000 candidates."""
+    import bench
+    g, cfg, _ = bench.build_workload("C5")
+    e1, ep = _engine(g, cfg, IPC_SPEC_WINDOW=1), _engine(g, cfg)
+    order = e1.candidate_order()[:3000]
+    r1, rp = _records(e1, order), _records(ep, order)
+    assert max(r[3] for r in r1) >= 500
+    _assert_bitwise(r1, rp)
+    assert np.array_equal(e1.current_poses().view(np.uint64), ep.current_poses().view(np.uint64))
