@@ -70,6 +70,14 @@ struct BandArgs {
     int bwb;                 // block half-bandwidth of the band loops
     int* abort_seen;         // device word: workgroup 0 publishes what it read from the host's abort word
     const double* zero;      // a word that holds 0.0 (entries outside the profile are read from it)
+    // Split ("twisted") factorisation: the band loops are cut into T = [0, s), M = [s, s + bwb + 1) and the rest; system 1
+    // (B / A / Lf / dinv above) holds T and M in their order + the wide loops, system 2 the rest and M in REVERSE order + the
+    // wide loops.  Both eliminate their own loops at the same time (two teams of workgroups), the Schur complement system 2
+    // leaves on M and the wide loops is added to system 1's, and system 1 finishes.  split_s < 0: one system, no split.
+    int split_s;
+    BandLayout B2;
+    double *A2, *Lf2, *dinv2;
+    unsigned* team_bar;      // [2] arrival counters of the two teams
 };
 
 // ---- grid-wide phase helpers --------------------------------------------------------------------------------------
@@ -244,7 +252,7 @@ __device__ __forceinline__ bool band_scan(double* arr, int K, int L, int ld, dou
 // ---- blocked Cholesky on the banded layout (cluster_persist.hpp::chol_tile / pchol_factor, rows by BandRows) ----------
 template <class AfterLoads>
 __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayout& B, const BandRows& TR, int k0, int nbk, bool has,
-                                           int bx, int by, const double* DT, double* panel, bool skip_next_diag, unsigned long long* prof,
+                                           int bx, int by, const double* DT, double* panel, int skip_until, unsigned long long* prof,
                                            AfterLoads after_loads)
 {
     const unsigned long long ts0 = prof_now();
@@ -278,7 +286,7 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
         const int i = TR.row(inr ? iv : 0), j = TR.row(inr ? jv : 0);
         bool in = inr && B.in(i, j);
         // (the next diagonal block belongs to workgroup 0, which reads its old values while this tile runs)
-        if (skip_next_diag && i < min(k1 + kCB, B.n)) in = false;
+        if (i < skip_until) in = false;                       // (skip_until: one past the next diagonal block, 0 = none)
         adr = in ? B.at32(i, j) : 0u;
         return in;
     };
@@ -334,9 +342,13 @@ __device__ __forceinline__ void bchol_tile(double* A, double* Lf, const BandLayo
 // Factor the banded system A (B.n unknowns, right-hand side = last dense row) into Lf / dinv; all G workgroups call it
 // together.  Workgroup 0 runs one block column ahead (next diagonal block), the others apply the tiles; G == 1: all of
 // it on the one workgroup.  Returns 0 or 1 + the first block column with a non-positive pivot.
-__device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, const BandLayout B, GridBar& gb, double* lds, bool& alive)
+// Columns c_begin .. c_end-1 only (c_end < B.n: a PARTIAL factorisation -- the Schur complement of the eliminated columns
+// stays in A, in place; c_begin > 0: continues one).  g / gb: this workgroup's index in, and the barrier of, the TEAM of
+// workgroups that work on this system (the split factorisation runs two teams on two systems side by side).
+__device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, const BandLayout B, GridBar& gb, int g, double* lds, bool& alive,
+                                         int c_begin, int c_end)
 {
-    const int n = B.n, g = blockIdx.x, G = gb.G, tid = threadIdx.x, sg = tid >> 8;
+    const int G = gb.G, tid = threadIdx.x, sg = tid >> 8;
     double* DT = lds + kLdsD;
     double (*Lrow)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(lds + kLdsR);
     double (*Dn)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsR + kLdsPanel);
@@ -356,24 +368,25 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
         if (tid < nbb) st_shared(&dinv[kb0 + tid], Dninv[tid]);
     };
     if (g == 0) {
-        const int nb0 = min(kCB, n);
+        const int nb0 = min(kCB, c_end - c_begin);
         for (int idx = tid; idx < kCB * kCB; idx += kPT) {
             const int r = idx % kCB, c = idx / kCB;
-            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[B.at32(r, c)]) : (r == c ? 1.0 : 0.0);
+            Dn[r][c] = (r < nb0 && c < nb0 && r >= c) ? ld_shared(&A[B.at32(c_begin + r, c_begin + c)]) : (r == c ? 1.0 : 0.0);
         }
         __syncthreads();
         bool ok = true;
         if (tid < 64) ok = potrf32_wave(Dn, Dninv);
         if (tid == 0) lds[kLdsMisc] = ok ? 0.0 : 1.0;
         __syncthreads();
-        if (lds[kLdsMisc] != 0.0) info = 1;
-        publish(0, nb0);
+        if (lds[kLdsMisc] != 0.0) info = c_begin + 1;
+        publish(c_begin, nb0);
         dn_to_dt(nb0);
     }
     alive = band_barrier(gb, false);
-    for (int k0 = 0; k0 < n && alive; k0 += kCB) {
+    for (int k0 = c_begin; k0 < c_end && alive; k0 += kCB) {
         const unsigned long long tw0 = prof_now();
-        const int nbk = min(kCB, n - k0), k1 = k0 + nbk;
+        const int nbk = min(kCB, c_end - k0), k1 = k0 + nbk;
+        const int nb2 = min(kCB, c_end - k1);                 // the next diagonal block (0: none -- the last column block of this call)
         const BandRows TR(B, k1);
         constexpr int kDtPass = kCB * kCB / kPT;
         double dtv[kDtPass];
@@ -410,15 +423,14 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
                 if (has) { while (rem >= nti - by) { rem -= nti - by; ++by; } }
                 if (base == 0)
                     bchol_tile(A, Lf, B, TR, k0, nbk, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
-                               G > 1 && has && by == 0 && rem == 0, gb.prof, write_dt);
+                               (G > 1 && has && by == 0 && rem == 0) ? k1 + nb2 : 0, gb.prof, write_dt);
                 else
                     bchol_tile(A, Lf, B, TR, k0, nbk, has, by + rem, by, DT, lds + kLdsR + sg * 2 * kLdsPanel,
-                               G > 1 && has && by == 0 && rem == 0, gb.prof, [] {});
+                               (G > 1 && has && by == 0 && rem == 0) ? k1 + nb2 : 0, gb.prof, [] {});
             }
             if (total == 0) write_dt();
         }
-        if (g == 0 && k1 < n) {
-            const int nb2 = min(kCB, n - k1);
+        if (g == 0 && nb2 > 0) {
             if (G == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -501,13 +513,35 @@ __device__ __noinline__ int bband_factor(double* A, double* Lf, double* dinv, co
 // L^T x = y (y = the last dense row of the factor), workgroup 0 only: cluster_persist.hpp::pchol_backsolve on the banded
 // layout.  Per block column (from the last): the dots with the already solved unknowns run over the rows of the column's
 // profile (BandRows without the right-hand side), their factor entries requested one block column ahead.
+// Where unknown i of a system sits in the solution vector of the whole problem (the order of the cluster's loops):
+//   mode 0  the system IS the problem;
+//   mode 1  first system of a split factorisation: its band unknowns are the problem's first ones, its dense unknowns (the
+//           wide loops) sit behind ALL band unknowns of the problem;
+//   mode 2  second system: the loops behind the split point in REVERSE order (unknown i = component i % d of loop
+//           nlb - 1 - i / d), then the same dense unknowns.
+struct BandXMap {
+    int mode, nb, d, nlb;
+    __device__ __forceinline__ int operator()(int i) const
+    {
+        if (mode == 0) return i;
+        if (i >= nb) return d * nlb + (i - nb);
+        return mode == 1 ? i : d * (nlb - 1 - i / d) + i % d;
+    }
+};
+
 // Two block columns' worth of factor entries are kept in flight (two register buffers, used alternately): a step's
 // arithmetic is ~1 us, a trip to memory 3 - 4, and one buffer ahead left every step waiting for its operands.
 struct BandBsBuf {
     static constexpr int NW = kPT / 64, CPW = (kCB + NW - 1) / NW, MAXM = 8, DPT = (kCB * kCB + kPT - 1) / kPT;
     double pre[CPW][MAXM], dpre[DPT], ypre;
 };
-__device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout B, double* x, double* lds, const double* zero)
+// L^T x = y for the columns c_begin .. c_end-1 of a system (y = the last dense row of the factor), one workgroup:
+// cluster_persist.hpp::pchol_backsolve on the banded layout.  The unknowns behind c_end must be solved already (they are
+// read from the solution vector through xm).  Per block column (from the last): the dots with the solved unknowns run over
+// the rows of the column's profile (BandRows without the right-hand side), their factor entries requested two block columns
+// ahead.
+__device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout B, double* x, const BandXMap xm, double* lds, const double* zero,
+                                             int c_begin, int c_end)
 {
     constexpr int NW = BandBsBuf::NW, CPW = BandBsBuf::CPW, MAXM = BandBsBuf::MAXM, DPT = BandBsBuf::DPT;
     double (*D)[kCB + 1] = reinterpret_cast<double (*)[kCB + 1]>(lds + kLdsD);
@@ -516,11 +550,16 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
     const int n = B.n;
     const bool x_in_lds = n <= kPSG * 2 * kLdsPanel;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31;
-    const int nblk = (n + kCB - 1) / kCB;
+    const int nblk = (c_end - c_begin + kCB - 1) / kCB;
+    if (nblk <= 0) return;
+    if (x_in_lds && c_end < n) {                              // the unknowns an earlier call solved
+        for (int i = c_end + tid; i < n; i += kPT) xs[i] = ld_shared(&x[xm(i)]);
+        __syncthreads();
+    }
     // entry (r, j) sits at j * (ldb - 1) + r for a band row, at j * ldb + (W - nb) + r for a dense row; entries outside
     // the profile are read from a word that holds 0.0, so the dots below need no mask
     auto prefetch = [&](int kb, BandBsBuf& Q) {
-        const int k0 = kb * kCB, nbk = min(kCB, n - k0), k1 = k0 + nbk;
+        const int k0 = c_begin + kb * kCB, nbk = min(kCB, c_end - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
         unsigned jb[CPW], jd[CPW];
@@ -554,7 +593,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
     // one block column: the dots with the solved unknowns, then (nxt >= 0) the request for block column nxt into the
     // buffer this step has just emptied, then the triangle
     auto step = [&](int kb, BandBsBuf& Q, int nxt) {
-        const int k0 = kb * kCB, nbk = min(kCB, n - k0), k1 = k0 + nbk;
+        const int k0 = c_begin + kb * kCB, nbk = min(kCB, c_end - k0), k1 = k0 + nbk;
         const BandRows TR(B, k1);
         const int Rm = TR.R - 1;
         double xr[MAXM];
@@ -564,7 +603,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
             if (64 * m < Rm) {                                // (wave-uniform)
                 const int v = lane + 64 * m;
                 const int rc = v < Rm ? TR.row(v) : -1;
-                const double xv = x_in_lds ? xs[rc >= 0 ? rc : 0] : ld_shared(&x[rc >= 0 ? rc : 0]);     // (beyond LDS: sc1 both ways, no reliance on this CU's L1)
+                const double xv = x_in_lds ? xs[rc >= 0 ? rc : 0] : ld_shared(&x[xm(rc >= 0 ? rc : 0)]);     // (beyond LDS: sc1 both ways, no reliance on this CU's L1)
                 xr[m] = rc >= 0 ? xv : 0.0;
             }
         }
@@ -579,7 +618,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
                     if (64 * m < Rm) acc += Q.pre[q][m] * xr[m];
                 for (int v = lane + 64 * MAXM; v < Rm; v += 64) {     // (profiles beyond 512 rows)
                     const int r = TR.row(v);
-                    if (B.in(r, k0 + c)) acc += ld_shared(&Lf[B.at32(r, k0 + c)]) * (x_in_lds ? xs[r] : ld_shared(&x[r]));
+                    if (B.in(r, k0 + c)) acc += ld_shared(&Lf[B.at32(r, k0 + c)]) * (x_in_lds ? xs[r] : ld_shared(&x[xm(r)]));
                 }
                 acc = wave_sum(acc);
                 t[c] = acc;
@@ -605,7 +644,7 @@ __device__ __noinline__ void bband_backsolve(const double* Lf, const BandLayout 
                 v = l == r ? xq : (l < r ? fma(-col[r], xq, v) : v);
             }
             if (lane < nbk) {
-                st_shared(&x[k0 + lane], v);
+                st_shared(&x[xm(k0 + lane)], v);
                 if (x_in_lds) xs[k0 + lane] = v;
             }
         }
@@ -627,9 +666,9 @@ __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* 
     extern __shared__ double lds[];
     GridBar gb{&ctl->bar, 0u, (int)gridDim.x, &ctl->error, nullptr};
     bool alive = true;
-    const int r = bband_factor(Q.A, Q.Lf, Q.dinv, Q.B, gb, lds, alive);
+    const int r = bband_factor(Q.A, Q.Lf, Q.dinv, Q.B, gb, (int)blockIdx.x, lds, alive, 0, Q.B.n);
     if (blockIdx.x == 0) {
-        bband_backsolve(Q.Lf, Q.B, x, lds, Q.zero);
+        bband_backsolve(Q.Lf, Q.B, x, BandXMap{0, 0, 1, 0}, lds, Q.zero, 0, Q.B.n);
         if (threadIdx.x == 0) *info = alive ? r : -1;
     }
 }
@@ -640,14 +679,39 @@ __global__ __launch_bounds__(kPT, 1) void bband_test_kernel(BandArgs Q, double* 
 template <class T>
 __device__ __forceinline__ void band_assemble_block(const typename T::Dev& Dv, const BandArgs& Q, int l1, int l2, int r)
 {
+    constexpr int d = T::kD;
     double* A = Q.A;
     const BandLayout B = Q.B;
+    // PLAIN stores, published by the fenced barrier behind the assembly: 8-byte write-through (sc1) stores are one fabric
+    // write each, and at 36 per block pair the assembly was bound by them (266 us per iteration at 11 000 pairs).
     // (a diagonal block comes as a full d x d block; the banded layout holds the lower triangle only -- an entry above
     // the diagonal would land in the previous column's dense rows)
-    // PLAIN stores, published by the fenced barrier behind the assembly: 8-byte write-through (sc1) stores are one fabric
-    // write each, and at 36 per block pair the assembly was bound by them (266 us per iteration at 11 000 pairs)
-    T::assemble_row(Dv, l1, l2, r, [&](int row, int col, double v) { if (row >= col) gptr(A)[B.at32(row, col)] = v; },
-                    [&](int col, double v) { gptr(A)[B.at32(B.n, col)] = v; });
+    if (Q.split_s < 0) {
+        T::assemble_row(Dv, l1, l2, r, [&](int row, int col, double v) { if (row >= col) gptr(A)[B.at32(row, col)] = v; },
+                        [&](int col, double v) { gptr(A)[B.at32(B.n, col)] = v; });
+        return;
+    }
+    // split: unknown indices arrive in the order of the loops (band loops by first vertex, then the wide ones); system 1
+    // keeps that order for its loops, system 2 holds its band loops reversed
+    double* A2 = Q.A2;
+    const BandLayout B2 = Q.B2;
+    const int nlb = Q.nlb, NB = d * nlb, nb1 = B.nb, ms = d * Q.split_s;       // ms: first unknown of M
+    auto to2 = [&](int i) { return i >= NB ? B2.nb + (i - NB) : d * (nlb - 1 - i / d) + i % d; };
+    auto to1 = [&](int i) { return i >= NB ? nb1 + (i - NB) : i; };
+    T::assemble_row(Dv, l1, l2, r,
+        [&](int row, int col, double v) {
+            if (row < col) return;
+            const bool col1 = col < nb1 || col >= NB;                         // the column's loop lives in system 1 (T, M or wide)
+            const bool row1 = row < nb1 || row >= NB;
+            if (col1 && row1) { gptr(A)[B.at32(to1(row), to1(col))] = v; return; }
+            if (col < ms) return;                                             // (a loop behind M against one in front of it: no overlap, never stored)
+            const int a = to2(row), b = to2(col);                            // system 2: reversed, so the later loop has the smaller index
+            gptr(A2)[B2.at32(max(a, b), min(a, b))] = v;
+        },
+        [&](int col, double v) {
+            if (col < nb1 || col >= NB) gptr(A)[B.at32(B.n, to1(col))] = v;
+            else gptr(A2)[B2.at32(B2.n, to2(col))] = v;
+        });
 }
 
 template <class T>
@@ -675,7 +739,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     const unsigned long long tk0 = prof_now();
     const int nidx = L + nl + 1, nblk = (nidx + 255) / 256;
     int n_commit = 0;
-    unsigned red_parity = 0;
+    unsigned red_parity = 0, team_target = 0;                 // (team_target: where this workgroup's team barrier stands, split factorisation)
 
     { const Dev Dv = view(0); band_for(L + 1, Gc, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
     alive = band_barrier(gb, true);
@@ -706,6 +770,19 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
             const int c = j % d;
             for (int o = covered - c; o < B.W; ++o) gptr(Q.A)[(size_t)j * B.ldb + o] = 0.0;
         }
+        if (Q.split_s >= 0) {
+            // system 2: the same for the columns of its own loops; the columns of M (reversed) and of the wide loops hold
+            // nothing of the system itself -- they collect the Schur complement of the elimination and start from zero
+            const BandLayout B2 = Q.B2;
+            const int own = B2.nb - B2.W;
+            for (int j = g * kPT + tid; j < own; j += Ga * kPT) {
+                const int c = j % d;
+                for (int o = covered - c; o < B2.W; ++o) gptr(Q.A2)[(size_t)j * B2.ldb + o] = 0.0;
+            }
+            const long zn = (long)(B2.n - own) * B2.ldb;
+            double* z0 = Q.A2 + (size_t)own * B2.ldb;
+            for (long q = (long)g * kPT + tid; q < zn; q += (long)Ga * kPT) gptr(z0)[q] = 0.0;
+        }
     };
     auto linearize = [&](double& bb, double& bHb, double& hh, double& bh) {
         unsigned long long t0 = prof_now();
@@ -719,13 +796,68 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
         alive = band_barrier(gb, true) && alive;             // (release / acquire: the system was written with plain stores)
         prof_add(P.prof, kProfAssemble, t0); t0 = prof_now();
         int info = 0;
-        if (alive) info = bband_factor(Q.A, Q.Lf, Q.dinv, B, gb, lds, alive);
-        prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
-        if (g == 0 && alive) {
-            const Dev Dv = view(vsel);
-            bband_backsolve(Q.Lf, B, Dv.rhs, lds, Q.zero);
-            if (tid == 0) __hip_atomic_store(&P.ctl->le_sel, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the solver's word, for everyone)
+        if (Q.split_s < 0) {
+            if (alive) info = bband_factor(Q.A, Q.Lf, Q.dinv, B, gb, g, lds, alive, 0, n);
+            prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
+            if (g == 0 && alive) {
+                const Dev Dv = view(vsel);
+                bband_backsolve(Q.Lf, B, Dv.rhs, BandXMap{0, 0, 1, 0}, lds, Q.zero, 0, n);
+            }
+        } else {
+            // Split factorisation: two teams eliminate the loops in front of / behind M at the same time (system 2 holds its
+            // loops in reverse order, so both run the same top-down band Cholesky), system 2's Schur complement on M and the
+            // wide loops is added to system 1's, team 0 finishes system 1; the back substitution runs M + wide first, then
+            // both halves side by side.  Half the dependent block columns of the single chain.
+            const BandLayout B2 = Q.B2;
+            const int Gt = G / 2, team = g / Gt, gt = g - team * Gt;
+            const int ms = d * Q.split_s, own2 = B2.nb - B2.W;
+            GridBar tb{&Q.team_bar[team], team_target, Gt, gb.error, team == 0 ? P.prof : nullptr};
+            int inf = 0;
+            if (alive) inf = team == 0 ? bband_factor(Q.A, Q.Lf, Q.dinv, B, tb, gt, lds, alive, 0, ms)
+                                       : bband_factor(Q.A2, Q.Lf2, Q.dinv2, B2, tb, gt, lds, alive, 0, own2);
+            if (team == 1 && gt == 0 && tid == 0) __hip_atomic_store(&P.ctl->cmd, inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = band_barrier(gb, false) && alive;
+            {
+                const int nc = B2.n - own2, nr = nc + 1;                  // columns of M (reversed) + wide; rows: the same + the right-hand side
+                auto to1 = [&](int i2) {                                 // an unknown of system 2 behind its own loops, in system 1
+                    if (i2 == B2.n) return B.n;
+                    if (i2 >= B2.nb) return B.nb + (i2 - B2.nb);
+                    return d * (Q.nlb - 1 - i2 / d) + i2 % d;
+                };
+                for (int q = g * kPT + tid; q < nc * nr; q += G * kPT) {
+                    const int cb = q / nr, ri = q - cb * nr;
+                    if (ri < cb) continue;
+                    const int i2 = own2 + ri, j2 = own2 + cb;
+                    const double u = ld_shared(&Q.A2[B2.at32(i2, j2)]);
+                    const int a = to1(i2), b = to1(j2);
+                    double* dst = &Q.A[B.at32(max(a, b), min(a, b))];
+                    st_shared(dst, ld_shared(dst) + u);
+                }
+            }
+            alive = band_barrier(gb, false) && alive;
+            int inf3 = 0;
+            if (team == 0 && alive) inf3 = bband_factor(Q.A, Q.Lf, Q.dinv, B, tb, gt, lds, alive, ms, n);
+            team_target = tb.target;
+            if (g == 0) {
+                const int inf2 = __hip_atomic_load(&P.ctl->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                info = inf ? inf : (inf2 ? inf2 : inf3);
+            }
+            prof_add(P.prof, kProfFactor, t0); t0 = prof_now();
+            const BandXMap xm1{1, B.nb, d, Q.nlb}, xm2{2, B2.nb, d, Q.nlb};
+            if (g == 0 && alive) {
+                const Dev Dv = view(vsel);
+                bband_backsolve(Q.Lf, B, Dv.rhs, xm1, lds, Q.zero, ms, n);
+            }
+            alive = band_barrier(gb, false) && alive;
+            if (g == 0 && alive) {
+                const Dev Dv = view(vsel);
+                bband_backsolve(Q.Lf, B, Dv.rhs, xm1, lds, Q.zero, 0, ms);
+            } else if (g == Gt && alive) {
+                const Dev Dv = view(vsel);
+                bband_backsolve(Q.Lf2, B2, Dv.rhs, xm2, lds, Q.zero, 0, own2);
+            }
         }
+        if (g == 0 && tid == 0) __hip_atomic_store(&P.ctl->le_sel, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the solver's word, for everyone)
         alive = band_barrier(gb, true) && alive;
         info = __hip_atomic_load(&P.ctl->le_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         prof_add(P.prof, kProfBacksolve, t0); t0 = prof_now();

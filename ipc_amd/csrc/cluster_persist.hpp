@@ -38,6 +38,7 @@ struct PersistCtl {                          // device memory, zeroed before eve
     int cmd;                                 // leader -> helpers: 1 = factor, 2 = exit
     int le_sel;                              // 1: the committed loop errors sit in the second buffer (commit swaps them)
     int error;                               // 1: a barrier timed out
+    unsigned team_bar[2];                    // band kernel, split factorisation: the two halves' own barriers
 };
 
 struct PersistOut {                          // result record (device, copied to pinned host memory behind the kernel)
@@ -1059,12 +1060,14 @@ public:
     int max_helpers = 39;                       // workgroups besides the leader (kLdsTotal = 141 824 bytes of LDS each: one per CU)
     // clusters of at least this many capacitance unknowns whose loops form a band go to cluster_band_kernel
     // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it (C1's 759, C2's 480 unknowns): the dense kernel, bit for bit as in rounds 3-4.
+    int band_split_min = 8;                     // IPC_BAND_SPLIT: split the factorisation of a band of at least this many half-widths of loops; 0: never
     int band_min_n = 1024;                      // (2 048 in the first round-5 runs: C4's first 700 candidates 5.6 s -> 3.9 s; at 1 000 unknowns the dense
                                                 // trailing update is already several rounds of tiles per block column, the band's is one)
 
     PersistSolver()
     {
         if (const char* e = getenv("IPC_BAND_MIN_N")) { if (*e) band_min_n = atoi(e); }
+        if (const char* e = getenv("IPC_BAND_SPLIT")) { if (*e) band_split_min = std::max(0, atoi(e)); }
     }
     ~PersistSolver() { release(); }
     bool last_was_band() const { return last_band_; }
@@ -1091,7 +1094,17 @@ public:
             band_.ldb = band_.W + band_.m; band_.n = n;
         }
         const std::vector<int>& mem = plan.use ? reordered : members;
-        IPC_CL_CHK(ensure(L, nl, plan.use ? 2 * band_.doubles() : 2 * ((size_t)n + 1) * n));
+        // Split factorisation (cluster_band.hpp, BandArgs::split_s): worth it from ~8 band widths of loops on
+        int split_s = -1;
+        if (plan.use && band_split_min > 0 && plan.nlb >= band_split_min * (plan.bwb + 1) && max_helpers >= 3) {
+            split_s = (plan.nlb - (plan.bwb + 1)) / 2;
+            const int m = band_.m, W = band_.W;
+            band_.nb = T::kD * (split_s + plan.bwb + 1); band_.n = band_.nb + m - 1;
+            band2_.nb = T::kD * (plan.nlb - split_s); band2_.m = m; band2_.W = W; band2_.ldb = W + m; band2_.n = band2_.nb + m - 1;
+        }
+        last_split_ = split_s >= 0;
+        const size_t band_doubles = split_s >= 0 ? 2 * (band_.doubles() + band2_.doubles()) : 2 * band_.doubles();
+        IPC_CL_CHK(ensure(L, nl, plan.use ? band_doubles : 2 * ((size_t)n + 1) * n));
         const int ld = L + 2;
         Dev& D = dev_;
         D.chain = chain; D.estride = estride; D.lo = lo; D.L = L; D.nl = nl; D.ld = ld;
@@ -1152,11 +1165,17 @@ public:
             const int want = std::max((tiles + kPSG - 1) / kPSG, std::min(24, (L + nl) / (4 * kPT)));
             G = 1 + std::min(max_helpers, want);
             G = std::max(1, std::min(G, resident_limit));
+            if (split_s >= 0) {                               // two teams of equal size
+                const int Gt = std::max(2, std::min(1 + want, std::min((max_helpers + 1) / 2, resident_limit / 2)));
+                G = 2 * Gt;
+            }
             static const bool band_debug = getenv("IPC_BAND_DEBUG") != nullptr;
             if (band_debug)
-                fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d\n", L, nl, plan.nlb, plan.bwb,
-                        n, band_.W, band_.m, G);
-            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8)};
+                fprintf(stderr, "[band] L %d loops %d (band %d, half-width %d blocks) n %d W %d m %d workgroups %d split at loop %d\n", L, nl, plan.nlb,
+                        plan.bwb, n, band_.W, band_.m, G, split_s);
+            double* A2 = d_S_ + 2 * band_.doubles();
+            BandArgs Q{band_, d_S_, d_S_ + band_.doubles(), d_dinv_, d_gpart_, d_gscan_, plan.nlb, plan.bwb, d_abort_seen_, reinterpret_cast<const double*>(d_abort_seen_ + 8),
+                       split_s, band2_, A2, A2 + band2_.doubles(), d_dinv_ + band_.n + kCB, d_ctl_->team_bar};
             hipLaunchKernelGGL(cluster_band_kernel<T>, dim3(G), dim3(kPT), sizeof(double) * kLdsTotal, st, D, D1, P, Q);
         } else {
             G = std::max(1, std::min(G, resident_limit));
@@ -1212,8 +1231,8 @@ private:
     hipStream_t st_ = nullptr;
     int capL_ = 0, capNl_ = 0, x_sel_ = 0, last_G_ = 1;
     size_t capS_ = 0;                           // doubles of d_S_ (system + factor: dense 2 (n + 1) n, banded 2 n (W + m))
-    bool aborted_ = false, timed_out_ = false, last_band_ = false;
-    BandLayout band_{};
+    bool aborted_ = false, timed_out_ = false, last_band_ = false, last_split_ = false;
+    BandLayout band_{}, band2_{};
     double device_us_ = 0.0;
     double *d_edge_ = nullptr, *d_loop_ = nullptr, *d_S_ = nullptr, *d_dinv_ = nullptr;
     double *d_gpart_ = nullptr, *d_gscan_ = nullptr;       // reduction partials / scan run totals of the band kernel
@@ -1267,7 +1286,7 @@ private:
             const size_t ld = (size_t)nL + 2, n = (size_t)T::kD * nN;
             IPC_CL_CHK(hipMalloc(&d_edge_, sizeof(double) * (T::kEdgeDoubles * ld + ld + nN)));
             IPC_CL_CHK(hipMalloc(&d_loop_, sizeof(double) * (T::kLoopDoubles * (size_t)nN + 8)));
-            IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (n + kCB)));
+            IPC_CL_CHK(hipMalloc(&d_dinv_, sizeof(double) * (2 * n + 4 * kCB)));      // (a split factorisation keeps two systems' pivots)
             IPC_CL_CHK(hipMalloc(&d_int_, sizeof(int) * LoopTables::capacity(nL, nN)));
             IPC_CL_CHK(hipMalloc(&d_gpart_, sizeof(double) * 2 * 8 * ((ld + nN + 255) / 256 + 2)));
             IPC_CL_CHK(hipMalloc(&d_gscan_, sizeof(double) * 27 * ((ld + 1023) / 1024 + 2)));

@@ -3038,7 +3038,7 @@ extern "C" int ipc_debug_band_solve(int nb, int m, int W, const double* system, 
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bband_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * kLdsTotal)));
     HIPCHK(hipMemset(ddinv + B.n + 32, 0, sizeof(double)));                 // (the word that holds 0.0)
-    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, ddinv + B.n + 32};
+    BandArgs Q{B, dA, dA + sz, ddinv, nullptr, nullptr, 0, 0, nullptr, ddinv + B.n + 32, -1, BandLayout{}, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(bband_test_kernel, dim3(workgroups), dim3(kPT), sizeof(double) * kLdsTotal, nullptr, Q, dx, dctl, dinfo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
