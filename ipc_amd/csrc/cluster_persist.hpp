@@ -1061,6 +1061,7 @@ public:
     // clusters of at least this many capacitance unknowns whose loops form a band go to cluster_band_kernel
     // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it (C1's 759, C2's 480 unknowns): the dense kernel, bit for bit as in rounds 3-4.
     int band_split_min = 8;                     // IPC_BAND_SPLIT: split the factorisation of a band of at least this many half-widths of loops; 0: never
+    int band_team_wgs = 0;                      // IPC_BAND_TEAM (experiments): workgroups per team of a split factorisation; 0: the rule in launch()
     int band_min_n = 1024;                      // (2 048 in the first round-5 runs: C4's first 700 candidates 5.6 s -> 3.9 s; at 1 000 unknowns the dense
                                                 // trailing update is already several rounds of tiles per block column, the band's is one)
 
@@ -1068,6 +1069,7 @@ public:
     {
         if (const char* e = getenv("IPC_BAND_MIN_N")) { if (*e) band_min_n = atoi(e); }
         if (const char* e = getenv("IPC_BAND_SPLIT")) { if (*e) band_split_min = std::max(0, atoi(e)); }
+        if (const char* e = getenv("IPC_BAND_TEAM")) { if (*e) band_team_wgs = std::max(0, atoi(e)); }
     }
     ~PersistSolver() { release(); }
     bool last_was_band() const { return last_band_; }
@@ -1096,7 +1098,7 @@ public:
         const std::vector<int>& mem = plan.use ? reordered : members;
         // Split factorisation (cluster_band.hpp, BandArgs::split_s): worth it from ~8 band widths of loops on
         int split_s = -1;
-        if (plan.use && band_split_min > 0 && plan.nlb >= band_split_min * (plan.bwb + 1) && max_helpers >= 3) {
+        if (plan.use && band_split_min > 0 && plan.nlb >= band_split_min * (plan.bwb + 1)) {   // (NOT a function of the helper count: results must not depend on it)
             split_s = (plan.nlb - (plan.bwb + 1)) / 2;
             const int m = band_.m, W = band_.W;
             band_.nb = T::kD * (split_s + plan.bwb + 1); band_.n = band_.nb + m - 1;
@@ -1162,11 +1164,16 @@ public:
             const int R = band_.W + band_.m, nti = (R + 63) / 64, tiles = nti * (nti + 1) / 2;
             // (more workgroups than the tiles need make every barrier slower: C4's first 1 500 candidates 17.5 s with 9, 21.6 s
             // with 20, 33.0 s with 40 workgroups per solve -- same digest)
-            const int want = std::max((tiles + kPSG - 1) / kPSG, std::min(24, (L + nl) / (4 * kPT)));
+            const int want_tiles = (tiles + kPSG - 1) / kPSG, want_chain = std::min(24, (L + nl) / (4 * kPT));
+            const int want = std::max(want_tiles, want_chain);
             G = 1 + std::min(max_helpers, want);
             G = std::max(1, std::min(G, resident_limit));
             if (split_s >= 0) {                               // two teams of equal size
-                const int Gt = std::max(2, std::min(1 + want, std::min((max_helpers + 1) / 2, resident_limit / 2)));
+                // (a team = the workgroups its tiles need; the chain phases run on both teams together.  Prefixes of C4 / C5 with 3 / 5 / 7 / 9 / 12
+                // workgroups per team: 18.5 / 13.9 / 15.4 / 13.3 / 14.1 s and 17.1 / 14.2 / 16.6 / 18.6 / 19.3 s, same digests -- C5 keeps 16 solves in
+                // flight and is bound by the CUs they hold, its expected rejects run on the reject helper limit: tools/band_team_sweep.sh)
+                const int team_rule = std::max(1 + want_tiles, (2 + want_chain) / 2);
+                const int Gt = std::max(1, std::min(band_team_wgs > 0 ? band_team_wgs : team_rule, std::min((max_helpers + 1) / 2, resident_limit / 2)));   // (two workgroups at least: one per team)
                 G = 2 * Gt;
             }
             static const bool band_debug = getenv("IPC_BAND_DEBUG") != nullptr;

@@ -225,10 +225,11 @@ def _assert_bitwise(a, b):
             assert np.float64(x).tobytes() == np.float64(y).tobytes() or (x != x and y != y), (q, ra, rb)
 
 
-@pytest.mark.parametrize("workload", ["C4s", "tiny"])
+@pytest.mark.parametrize("workload", ["C4s", "tiny", "C4m"])
 def test_band_kernel_pipeline_and_helper_counts_change_no_bit(workload):
     """One at a time with 0 / 3 / 39 helpers and the 16-deep pipeline: identical records and poses (the reductions and
-    prefix sums add in an order that does not depend on the number of workgroups)."""
+    prefix sums add in an order that does not depend on the number of workgroups).  C4m's band is long enough for the split
+    factorisation (two teams; one workgroup each when there are no helpers)."""
     import bench
     g, cfg, _ = bench.build_workload(workload)
     engs = [_engine(g, cfg, IPC_BAND_MIN_N=0, IPC_SPEC_WINDOW=1, IPC_PERSIST_HELPERS=h) for h in (0, 3, 39)]
