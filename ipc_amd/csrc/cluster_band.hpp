@@ -743,6 +743,7 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
 
     { const Dev Dv = view(0); band_for(L + 1, Gc, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
     alive = band_barrier(gb, true);
+    prof_add(P.prof, kProfRest, tk0);                         // ("rest": the start -- initial poses and the first barrier, i.e. until the last workgroup of the launch has a CU)
 
     auto evaluate = [&](bool trial) {
         double tot[1];

@@ -1061,6 +1061,10 @@ public:
     // clusters of at least this many capacitance unknowns whose loops form a band go to cluster_band_kernel
     // (cluster_band.hpp); IPC_BAND_MIN_N, negative = never.  Below it (C1's 759, C2's 480 unknowns): the dense kernel, bit for bit as in rounds 3-4.
     int band_split_min = 8;                     // IPC_BAND_SPLIT: split the factorisation of a band of at least this many half-widths of loops; 0: never
+    int band_team_reject = 0;                   // IPC_BAND_TEAM_REJECT (experiments; 0: off): workgroups per team of a banded solve the caller expects to reject
+                                                // (`economy`).  Measured with the per-XCD budget of spec_pump: C4 prefix 23.1 s without, 24.8 / 27.8 / 29.5 s
+                                                // with 5 / 6 / 7 -- a reject on fewer workgroups holds its slot longer, and the run is bound by the accept chain
+    bool economy = false;                       // set per launch by the pipeline (scheduling only: results do not depend on the workgroup count)
     int band_team_wgs = 0;                      // IPC_BAND_TEAM (experiments): workgroups per team of a split factorisation; 0: the rule in launch()
     int band_min_n = 1024;                      // (2 048 in the first round-5 runs: C4's first 700 candidates 5.6 s -> 3.9 s; at 1 000 unknowns the dense
                                                 // trailing update is already several rounds of tiles per block column, the band's is one)
@@ -1070,6 +1074,7 @@ public:
         if (const char* e = getenv("IPC_BAND_MIN_N")) { if (*e) band_min_n = atoi(e); }
         if (const char* e = getenv("IPC_BAND_SPLIT")) { if (*e) band_split_min = std::max(0, atoi(e)); }
         if (const char* e = getenv("IPC_BAND_TEAM")) { if (*e) band_team_wgs = std::max(0, atoi(e)); }
+        if (const char* e = getenv("IPC_BAND_TEAM_REJECT")) { if (*e) band_team_reject = std::max(0, atoi(e)); }
     }
     ~PersistSolver() { release(); }
     bool last_was_band() const { return last_band_; }
@@ -1168,12 +1173,14 @@ public:
             const int want = std::max(want_tiles, want_chain);
             G = 1 + std::min(max_helpers, want);
             G = std::max(1, std::min(G, resident_limit));
+            if (economy && band_team_reject > 0) G = std::min(G, 2 * band_team_reject);
             if (split_s >= 0) {                               // two teams of equal size
                 // (a team = the workgroups its tiles need; the chain phases run on both teams together.  Prefixes of C4 / C5 with 3 / 5 / 7 / 9 / 12
                 // workgroups per team: 18.5 / 13.9 / 15.4 / 13.3 / 14.1 s and 17.1 / 14.2 / 16.6 / 18.6 / 19.3 s, same digests -- C5 keeps 16 solves in
                 // flight and is bound by the CUs they hold, its expected rejects run on the reject helper limit: tools/band_team_sweep.sh)
                 const int team_rule = std::max(1 + want_tiles, (2 + want_chain) / 2);
-                const int Gt = std::max(1, std::min(band_team_wgs > 0 ? band_team_wgs : team_rule, std::min((max_helpers + 1) / 2, resident_limit / 2)));   // (two workgroups at least: one per team)
+                int Gt = std::max(1, std::min(band_team_wgs > 0 ? band_team_wgs : team_rule, std::min((max_helpers + 1) / 2, resident_limit / 2)));
+                if (economy && band_team_reject > 0) Gt = std::min(Gt, band_team_reject);   // (two workgroups at least: one per team)
                 G = 2 * Gt;
             }
             static const bool band_debug = getenv("IPC_BAND_DEBUG") != nullptr;

@@ -660,6 +660,7 @@ struct ipc_engine {
         int state = -1;                                // index of the pose state it started from (spec_states)
         int launch_id = 0;
         int busy_wgs = 0;                              // workgroups of the last launch until its `done` completes (also after an abort)
+        int expect = -1;                               // the verdict the scheduler expected when it launched the solve (1 accept, 0 reject, -1 none): IPC_SPEC_STATS
         std::chrono::steady_clock::time_point t_launch;   // (IPC_SPEC_STATS: launch-to-collect time per dog-leg iteration)
         int lo = 0, hi = 0, nclu = 0;
         double th = 0.0;
@@ -707,6 +708,14 @@ struct ipc_engine {
     double pred_k = 30.0;                              // predicted accept: own chi2 at the state it starts from <= pred_k x the slow threshold (IPC_SPEC_PREDICT; 0: off; 10 until round 5: on C5 a third of the mispredicted accepts -- each drops the ~15 solves in flight behind it -- lie between 10 and 30, C5 prefix 23.0 -> 21.5 s, C2 and C4 unchanged)
     std::vector<double> pred_last;                     // the newest predictions that have arrived (stand-in while a state's own are on their way)
     int spec_behind = 1;                               // IPC_SPEC_BEHIND (C1: 0.56 / 0.59 / 0.59 / 0.63 s with 0 / 1 / 2 / 4 -- every launch is host time on the accept chain; C2, C4m: within noise)
+    // IPC_SPEC_HEDGE: while an expected accept is out, the NEXT expected accepts in line (this many) are started as well, on the state
+    // in front of it -- the chain's continuation if it rejects after all (C4: one expected accept in ten does, and takes ten times as
+    // long as an accept to say so; the chain stood still for the 2.5 accept times of the gate: the tail of the run's accept-to-
+    // next-solve gaps, median 0.3 ms, 90th percentile 18 ms).  -1: on when an accepted solve takes >= 3 ms (C1 / C2: a launch is
+    // host time on the chain and the solves are 2 ms).  MEASURED: no gain -- C4 prefix 26.1 / 26.6 / 27.6 s and C5 13.5 / 13.7 / 13.9 s with 0 / 1 / 2,
+    // one barrier time-out with 3: what the hedges win on the runs of rejecting expected accepts the crowding takes from every
+    // other solve (an accept solve takes 10 ms on the device with ten solves in flight, 15 ms with sixteen) -- default 0
+    int spec_hedge = 0;
     int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
                                                        // the rejects are the bulk of the work and independent of each other -- many of them
                                                        // side by side; the expected accepts are the serial chain -- each as fast as it can be
@@ -724,6 +733,10 @@ struct ipc_engine {
     // IPC_SPEC_STATS: why slots stood empty, in slot x pump calls (the caller's thread spins on the pump, so this is time):
     // [0] behind an expected accept, [1] look-ahead used up / no candidate left, [2] CU budget, [3] cluster beyond the persistent solver, [4] total slot-pumps
     unsigned long long idle_why[5] = {0, 0, 0, 0, 0};
+    hipStream_t pred_stream = nullptr;                 // the predictions of new tentative states (process pool, not owned)
+    FILE* spec_log = nullptr;                          // IPC_SPEC_LOG=<file>: one line per finished solve / tentative state / verdict handed out (tools/spec_chain.py)
+    std::chrono::steady_clock::time_point spec_log_t0;
+    long pred_conf[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // [expectation + 1][verdict] over the solves whose result was kept (IPC_SPEC_STATS)
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
@@ -874,6 +887,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (const char* pk = getenv("IPC_SPEC_PREDICT")) { if (*pk) h->pred_k = std::max(0.0, atof(pk)); }
     if (const char* hr = getenv("IPC_PERSIST_HELPERS_REJECT")) { if (*hr) h->helper_limit_reject = std::max(0, atoi(hr)); }
     if (const char* sb = getenv("IPC_SPEC_BEHIND")) { if (*sb) h->spec_behind = std::max(0, std::min(64, atoi(sb))); }
+    if (const char* lg = getenv("IPC_SPEC_LOG")) { if (*lg) { h->spec_log = fopen(lg, "w"); h->spec_log_t0 = std::chrono::steady_clock::now(); } }
+    if (const char* hg = getenv("IPC_SPEC_HEDGE")) { if (*hg) h->spec_hedge = std::max(-1, std::min(8, atoi(hg))); }
     if (const char* gr = getenv("IPC_SPEC_GATE_MS")) { if (*gr) h->gate_release_ms = std::max(0.0, atof(gr)); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
         if (!strcmp(cm, "host")) h->persist = false;
@@ -1058,14 +1073,17 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
                         "\"accept_solves\": %ld, \"accept_us_per_iteration\": %.1f, \"accept_ms_per_solve\": %.2f, "
                         "\"reject_solves\": %ld, \"reject_us_per_iteration\": %.1f, \"reject_ms_per_solve\": %.2f, "
                         "\"accept_ms_per_solve_on_the_device\": %.2f, \"reject_ms_per_solve_on_the_device\": %.2f, "
-                        "\"empty_slot_share\": {\"behind_an_expected_accept\": %.3f, \"no_candidate_within_the_look_ahead\": %.3f, \"cu_budget\": %.3f, \"cluster_too_large\": %.3f}}}\n",
+                        "\"empty_slot_share\": {\"behind_an_expected_accept\": %.3f, \"no_candidate_within_the_look_ahead\": %.3f, \"cu_budget\": %.3f, \"cluster_too_large\": %.3f}, "
+                        "\"kept_results_by_expectation\": {\"expected_accept\": {\"accepted\": %ld, \"rejected\": %ld}, \"expected_reject\": {\"accepted\": %ld, \"rejected\": %ld}, \"none\": {\"accepted\": %ld, \"rejected\": %ld}}}}\n",
                 h->spec_window, h->spec_active, h->stream_concurrency, h->persist_timeouts, h->spec_ahead, h->spec_launches, h->spec_hits, h->spec_wasted, h->spec_tentative, h->spec_promoted,
                 h->spec_t_total, h->spec_t_launch, h->spec_t_tent,
                 h->st_acc_n, 1e6 * h->st_acc_s / std::max(1L, h->st_acc_it), 1e3 * h->st_acc_s / std::max(1L, h->st_acc_n),
                 h->st_rej_n, 1e6 * h->st_rej_s / std::max(1L, h->st_rej_it), 1e3 * h->st_rej_s / std::max(1L, h->st_rej_n),
                 1e3 * h->st_acc_dev_s / std::max(1L, h->st_acc_n), 1e3 * h->st_rej_dev_s / std::max(1L, h->st_rej_n),
                 (double)h->idle_why[0] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[1] / std::max(1ull, h->idle_why[4]),
-                (double)h->idle_why[2] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[3] / std::max(1ull, h->idle_why[4]));
+                (double)h->idle_why[2] / std::max(1ull, h->idle_why[4]), (double)h->idle_why[3] / std::max(1ull, h->idle_why[4]),
+                h->pred_conf[2][1], h->pred_conf[2][0], h->pred_conf[1][1], h->pred_conf[1][0], h->pred_conf[0][1], h->pred_conf[0][0]);
+    if (h->spec_log) fclose(h->spec_log);
     if (h->ev_commit) hipEventDestroy(h->ev_commit);
     if (h->h_abort) hipHostFree(h->h_abort);
     delete h->persist2;
@@ -2412,7 +2430,7 @@ struct SpecTimer {
     explicit SpecTimer(double& a) : acc(a) {}
     ~SpecTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_reject)
+static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_reject, int expect)
 {
     SpecTimer tm(h->spec_t_launch);
     ipc_engine::SpecSlot& sl = h->slots[q];
@@ -2420,7 +2438,7 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_rej
     ipc_engine::SpecState& S = h->spec_states[si];
     if (h->cand_event) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_cand, 0));  // (records ipc_append_candidate wrote on own_stream)
     const ClusterSpec c = cluster_of(h, k, S.cns);
-    sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th;
+    sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th; sl.expect = expect;
     // (ids only grow, per slot too: the kernels give up when their slot's word has reached their id, so an abort also
     // reaches a launch that was still queued behind another aborted one when the word moved on)
     sl.launch_id = h->next_launch_id++;
@@ -2436,6 +2454,7 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_rej
         helpers = std::min(helpers, std::max(h->helper_limit_reject, (int)(0.45 * wanted)));
     }
     if (h->dim == 3) sl.s3->max_helpers = helpers; else sl.s2->max_helpers = helpers;
+    if (h->dim == 3) sl.s3->economy = expect_reject; else sl.s2->economy = expect_reject;
     if (h->dim == 3) {
         sl.s3->launch_id = sl.launch_id;
         HIPCHK(sl.s3->launch(sl.st, h->d_chain, h->estride, h->d_cand, h->cstride, S.d_poses, h->V, c.lo, c.hi, c.members,
@@ -2475,11 +2494,16 @@ static int spec_make_tentative(ipc_engine* h, int p, int q)
     }
     HIPCHK(hipEventRecord(T.ready, sl.st));
     T.has_ready = true;
-    if (int rc = spec_predict_state(h, t, sl.st)) return rc;
+    // (on a stream of its own: the next solve on the new state often lands on this very slot's stream, and the prediction
+    // kernel -- 35 small workgroups on a GPU full of persistent ones -- took 2.2 ms on average on C4 in front of it)
+    if (!h->pred_stream) HIPCHK(pipeline_stream(h->device, (int)h->slots.size(), &h->pred_stream));
+    HIPCHK(hipStreamWaitEvent(h->pred_stream, T.ready, 0));
+    if (int rc = spec_predict_state(h, t, h->pred_stream)) return rc;
     T.cns = P.cns;
     if (std::find(T.cns.begin(), T.cns.end(), h->porder[p]) != T.cns.end()) h->cns_dups = true;
     T.cns.push_back(h->porder[p]);
     T.pos = p;
+    if (h->spec_log) fprintf(h->spec_log, "tentative,%.0f,%d,%d\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->spec_log_t0).count(), p, h->porder[p]);
     h->tent.push_back(t);
     R.child = t;
     ++h->spec_tentative;
@@ -2585,6 +2609,12 @@ static int spec_pump(ipc_engine* h)
         const int p = sl.pos;
         --h->spec_states[sl.state].users;
         const bool stale = aborted || p < h->spec_head || sl.state != spec_state_at(h, p);
+        if (h->spec_log) {
+            const auto us = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t - h->spec_log_t0).count(); };
+            fprintf(h->spec_log, "solve,%.0f,%.0f,%d,%d,%d,%d,%d,%d,%d,%d,%.0f\n", us(sl.t_launch), us(std::chrono::steady_clock::now()), p, sl.cand, sl.expect,
+                    h->spec_states[sl.state].pos, stale ? (aborted ? 2 : 1) : 0, !(o.max_chi2 > sl.th) ? 1 : 0, o.iterations, sl.nclu,
+                    h->dim == 3 ? sl.s3->device_us() : sl.s2->device_us());
+        }
         sl.cand = -1;
         if (stale) { ++h->spec_wasted; continue; }
         ipc_engine::SpecResult& R = h->spec_res[p];
@@ -2592,6 +2622,7 @@ static int spec_pump(ipc_engine* h)
         R.valid = true; R.state = sl.state; R.lo = sl.lo; R.hi = sl.hi; R.nclu = sl.nclu; R.o = o;
         R.retry_host = lost || ((o.flags & 2) && h->lm_retry);                // (decided when its turn comes, by the host-driven solver)
         R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
+        ++h->pred_conf[sl.expect + 1][R.agree ? 1 : 0];
         {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - sl.t_launch).count();
             const double dev = 1e-6 * (h->dim == 3 ? sl.s3->device_us() : sl.s2->device_us());
@@ -2644,6 +2675,8 @@ static int spec_pump(ipc_engine* h)
     int gate_hi = -1;                                  // its later vertex: the candidates that END there too may be asked for before it (cmpTime
                                                        // leaves their order open, src/utils.cpp:379-389), so they are not "behind" it
     int behind = 0;                                    // solves in flight behind it
+    int chain_out = 0;                                 // (first scan) expected accepts in flight, gate and hedges
+    const int hedge = h->spec_hedge >= 0 ? h->spec_hedge : (h->st_acc_n >= 8 && h->st_acc_s >= 3e-3 * (double)h->st_acc_n ? 1 : 0);
     for (int lp = h->spec_head; lp < end; ++lp) {
         if (h->spec_res[lp].valid) continue;
         int q = -1, running = 0, busy = 0, at = -1;
@@ -2664,23 +2697,36 @@ static int spec_pump(ipc_engine* h)
         if (at >= 0) {
             if (gated) behind += !tied;
             else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) { gated = true; gate_hi = h->h_hi[cand_lp]; }
-            if (pa_only && gated) break;               // (the chain is running)
+            if (pa_only && gated && pa && ++chain_out > hedge) break;   // (the chain is running)
             continue;
         }
         if (pa_only && !pa) continue;
         if (q < 0 || running >= target) { why = -1; break; }
-        if (gated && !tied && behind >= h->spec_behind) { why = 0; break; }
+        if (gated && !tied && behind >= h->spec_behind && !(pa_only && hedge > 0)) { why = 0; break; }     // (a hedge is not one of the `behind`)
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
         for (int i = 0; i < B; ++i) if (i != q) busy += h->slots[i].busy_wgs;
         // (an expected reject with next to nothing beside it -- a caller that appends one candidate per check -- is the critical path too)
         const bool expect_reject = (cur_pred || file_pred) && !pa && running >= 4;
-        const int helpers = std::min(h->helper_limit, h->n_cu - 8 - busy - 1);
+        // ... and per XCD: workgroup b of a launch goes to XCD b % 8 (observed placement, MI355X guide: used for speed only -- a wrong
+        // guess costs time, never a result), so a launch of 18 puts 3 on XCDs 0 and 1 and 2 on the others, and sixteen of them ask
+        // XCD 0 for 48 CUs of its 32: the last workgroups of a launch then wait for a CU while the others spin at the first
+        // barrier (IPC_PERSIST_PROF "rest": a quarter of the leader's time on C4 with the global count alone)
+        int gmax = 1 << 30;
+        {
+            const int per_xcd = h->n_cu / 8 - 1;
+            for (int x = 0; x < 8; ++x) {
+                int load = 0;
+                for (int i = 0; i < B; ++i) if (i != q && h->slots[i].busy_wgs > x) load += (h->slots[i].busy_wgs - x + 7) / 8;
+                gmax = std::min(gmax, 8 * std::max(0, per_xcd - load) + x);
+            }
+        }
+        const int helpers = std::min(std::min(h->helper_limit, gmax - 1), h->n_cu - 8 - busy - 1);
         if (helpers < std::min(8, h->helper_limit) && running > 0) { why = 2; break; }        // (wait for a solve to leave)
         const int tip = spec_state_at(h, lp);
         if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) { why = 3; break; }
-        if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject)) return rc;
+        if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject, (cur_pred || file_pred) ? (pa ? 1 : 0) : -1)) return rc;
         if (gated) behind += !tied;
         else if (pa) { gated = true; gate_hi = h->h_hi[cand_lp]; }
         if (pa_only) break;
@@ -2755,6 +2801,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
     ipc_engine::SpecResult R = h->spec_res[p];
     h->spec_res[p].valid = false;
     ++h->spec_hits;
+    if (h->spec_log) fprintf(h->spec_log, "verdict,%.0f,%d,%d,%d\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->spec_log_t0).count(), p, k, R.agree ? 1 : 0);
     ClusterOut o = R.o;
     const double th = R.nclu ? h->prm.slow_reject_th : h->prm.fast_reject_th;
     bool agree = R.agree;
