@@ -741,8 +741,17 @@ __global__ __launch_bounds__(kPT, 1) void cluster_band_kernel(typename T::Dev D0
     int n_commit = 0;
     unsigned red_parity = 0, team_target = 0;                 // (team_target: where this workgroup's team barrier stands, split factorisation)
 
+    if (P.prof && tid == 0) atomicMax(&P.ctl->last_start, (tk0 << 8) | (unsigned long long)(g & 255));
     { const Dev Dv = view(0); band_for(L + 1, Gc, [&](int i) { T::load_initial(Dv, P.src, P.src_ld, i); }); }
     alive = band_barrier(gb, true);
+    if (P.prof && tid == 0 && g == 0) {
+        const unsigned long long v = __hip_atomic_load(&P.ctl->last_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long skew = (v >> 8) > tk0 ? (v >> 8) - tk0 : 0ull;
+        P.prof[kProfStartSkew] += skew;
+        if (skew > 100000ull) P.prof[kProfStartSkewXcd01] += skew;      // (launches whose last workgroup came more than 1 ms late)
+        P.prof[kProfStartLaunches] += 1;
+        if (skew > 100000ull) P.prof[kProfHandoff] += 100;                // (their number, x 1 us)
+    }
     prof_add(P.prof, kProfRest, tk0);                         // ("rest": the start -- initial poses and the first barrier, i.e. until the last workgroup of the launch has a CU)
 
     auto evaluate = [&](bool trial) {

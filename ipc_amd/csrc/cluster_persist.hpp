@@ -39,6 +39,7 @@ struct PersistCtl {                          // device memory, zeroed before eve
     int le_sel;                              // 1: the committed loop errors sit in the second buffer (commit swaps them)
     int error;                               // 1: a barrier timed out
     unsigned team_bar[2];                    // band kernel, split factorisation: the two halves' own barriers
+    unsigned long long last_start;           // IPC_PERSIST_PROF: (clock << 8 | block) of the workgroup that started last
 };
 
 struct PersistOut {                          // result record (device, copied to pinned host memory behind the kernel)
@@ -76,6 +77,7 @@ struct GridBar { unsigned* ctr; unsigned target; int G; int* error; unsigned lon
 enum { kProfTotal = 0, kProfPre, kProfHandoff, kProfAssemble, kProfFactor, kProfFactorWork, kProfFactorWait, kProfBacksolve,
        kProfPost, kProfTrial, kProfRest, kProfIterations, kProfSteps,
        kProfHelpDT, kProfHelpSolve, kProfHelpUpdate, kProfHelpWait, kProfLookLoad, kProfLookSolve, kProfLookFill, kProfLookPotrf, kProfLookPub, kProfBsDots, kProfBsPrefetch, kProfBsSync, kProfBsTri,
+       kProfStartSkew, kProfStartSkewXcd01, kProfStartLaunches,             // band kernel: workgroup 0 start -> start of the LAST workgroup of the launch; the part of it in launches where that is over 1 ms (their number: "handoff"); launches
        kProfTileBlock, kProfTileSelect, kProfTileTrsm, kProfTileStore,      // band kernel, first tile workgroup: until the column's block has arrived / operands selected / panel solve / stores drained
        kProfN };
 __device__ __forceinline__ unsigned long long prof_now() { return wall_clock64(); }

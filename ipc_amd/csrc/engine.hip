@@ -715,6 +715,7 @@ struct ipc_engine {
     // host time on the chain and the solves are 2 ms).  MEASURED: no gain -- C4 prefix 26.1 / 26.6 / 27.6 s and C5 13.5 / 13.7 / 13.9 s with 0 / 1 / 2,
     // one barrier time-out with 3: what the hedges win on the runs of rejecting expected accepts the crowding takes from every
     // other solve (an accept solve takes 10 ms on the device with ten solves in flight, 15 ms with sixteen) -- default 0
+    int xcd_cus = 0;                                   // IPC_SPEC_XCD_CUS: workgroups of solves per XCD (0: its CUs less one)
     int spec_hedge = 0;
     int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
                                                        // the rejects are the bulk of the work and independent of each other -- many of them
@@ -888,6 +889,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (const char* hr = getenv("IPC_PERSIST_HELPERS_REJECT")) { if (*hr) h->helper_limit_reject = std::max(0, atoi(hr)); }
     if (const char* sb = getenv("IPC_SPEC_BEHIND")) { if (*sb) h->spec_behind = std::max(0, std::min(64, atoi(sb))); }
     if (const char* lg = getenv("IPC_SPEC_LOG")) { if (*lg) { h->spec_log = fopen(lg, "w"); h->spec_log_t0 = std::chrono::steady_clock::now(); } }
+    if (const char* xc = getenv("IPC_SPEC_XCD_CUS")) { if (*xc) h->xcd_cus = std::max(0, atoi(xc)); }
     if (const char* hg = getenv("IPC_SPEC_HEDGE")) { if (*hg) h->spec_hedge = std::max(-1, std::min(8, atoi(hg))); }
     if (const char* gr = getenv("IPC_SPEC_GATE_MS")) { if (*gr) h->gate_release_ms = std::max(0.0, atof(gr)); }
     if (const char* cm = getenv("IPC_CLUSTER_MODE")) {
@@ -1047,10 +1049,10 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
         static const char* names[kProfN] = {"total", "pre", "handoff", "assemble", "factor", "factor_work", "factor_wait", "backsolve",
                                             "post", "trial", "rest", "iterations", "steps", "help_dt", "help_solve", "help_update", "help_wait",
                                             "look_load", "look_solve", "look_fill", "look_potrf", "look_publish", "bs_dots", "bs_prefetch", "bs_sync", "bs_triangle",
-                                            "tile_block", "tile_select", "tile_trsm", "tile_store"};
+                                            "start_skew", "start_skew_of_launches_over_1_ms", "band_launches", "tile_block", "tile_select", "tile_trsm", "tile_store"};
         fprintf(stderr, "{\"persist_profile_us\": {");
         for (int k = 0; k < kProfN; ++k)
-            fprintf(stderr, "%s\"%s\": %.1f", k ? ", " : "", names[k], (k == kProfIterations || k == kProfSteps) ? (double)p[k] : p[k] * 0.01);
+            fprintf(stderr, "%s\"%s\": %.1f", k ? ", " : "", names[k], (k == kProfIterations || k == kProfSteps || k == kProfStartLaunches) ? (double)p[k] : p[k] * 0.01);
         fprintf(stderr, "}}\n");
         hipFree(h->d_prof);
     }
@@ -2715,7 +2717,7 @@ static int spec_pump(ipc_engine* h)
         // barrier (IPC_PERSIST_PROF "rest": a quarter of the leader's time on C4 with the global count alone)
         int gmax = 1 << 30;
         {
-            const int per_xcd = h->n_cu / 8 - 1;
+            const int per_xcd = h->xcd_cus > 0 ? h->xcd_cus : h->n_cu / 8 - 1;
             for (int x = 0; x < 8; ++x) {
                 int load = 0;
                 for (int i = 0; i < B; ++i) if (i != q && h->slots[i].busy_wgs > x) load += (h->slots[i].busy_wgs - x + 7) / 8;
