@@ -664,6 +664,7 @@ struct ipc_engine {
         std::chrono::steady_clock::time_point t_launch;   // (IPC_SPEC_STATS: launch-to-collect time per dog-leg iteration)
         int lo = 0, hi = 0, nclu = 0;
         double th = 0.0;
+        double pred_ratio = -1.0;                      // the candidate's own chi2 at the state it starts from / the slow threshold (IPC_SPEC_LOG)
     };
     struct SpecState {                                 // a pose state solves start from
         double* d_poses = nullptr;                     // d_cur (not owned) or a buffer of its own, [5 | 12][V]
@@ -715,6 +716,8 @@ struct ipc_engine {
     // host time on the chain and the solves are 2 ms).  MEASURED: no gain -- C4 prefix 26.1 / 26.6 / 27.6 s and C5 13.5 / 13.7 / 13.9 s with 0 / 1 / 2,
     // one barrier time-out with 3: what the hedges win on the runs of rejecting expected accepts the crowding takes from every
     // other solve (an accept solve takes 10 ms on the device with ten solves in flight, 15 ms with sixteen) -- default 0
+    double uncertain_from = 0.0;                       // IPC_SPEC_UNCERTAIN: an expected accept whose own chi2 is above this x the slow threshold is a coin toss (C4: 107 accepted,
+                                                       // 107 rejected between 3 and 30) -- the next expected accept is started beside it instead of behind it.  0: off
     int xcd_cus = 0;                                   // IPC_SPEC_XCD_CUS: workgroups of solves per XCD (0: its CUs less one)
     int spec_hedge = 0;
     int helper_limit_reject = 8;                       // helper workgroups of a solve that is expected to reject (IPC_PERSIST_HELPERS_REJECT):
@@ -889,6 +892,7 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     if (const char* hr = getenv("IPC_PERSIST_HELPERS_REJECT")) { if (*hr) h->helper_limit_reject = std::max(0, atoi(hr)); }
     if (const char* sb = getenv("IPC_SPEC_BEHIND")) { if (*sb) h->spec_behind = std::max(0, std::min(64, atoi(sb))); }
     if (const char* lg = getenv("IPC_SPEC_LOG")) { if (*lg) { h->spec_log = fopen(lg, "w"); h->spec_log_t0 = std::chrono::steady_clock::now(); } }
+    if (const char* un = getenv("IPC_SPEC_UNCERTAIN")) { if (*un) h->uncertain_from = std::max(0.0, atof(un)); }
     if (const char* xc = getenv("IPC_SPEC_XCD_CUS")) { if (*xc) h->xcd_cus = std::max(0, atoi(xc)); }
     if (const char* hg = getenv("IPC_SPEC_HEDGE")) { if (*hg) h->spec_hedge = std::max(-1, std::min(8, atoi(hg))); }
     if (const char* gr = getenv("IPC_SPEC_GATE_MS")) { if (*gr) h->gate_release_ms = std::max(0.0, atof(gr)); }
@@ -2432,7 +2436,7 @@ struct SpecTimer {
     explicit SpecTimer(double& a) : acc(a) {}
     ~SpecTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_reject, int expect)
+static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_reject, int expect, double pred_ratio = -1.0)
 {
     SpecTimer tm(h->spec_t_launch);
     ipc_engine::SpecSlot& sl = h->slots[q];
@@ -2440,7 +2444,7 @@ static int spec_launch(ipc_engine* h, int q, int p, int helpers, bool expect_rej
     ipc_engine::SpecState& S = h->spec_states[si];
     if (h->cand_event) HIPCHK(hipStreamWaitEvent(sl.st, h->ev_cand, 0));  // (records ipc_append_candidate wrote on own_stream)
     const ClusterSpec c = cluster_of(h, k, S.cns);
-    sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th; sl.expect = expect;
+    sl.cand = k; sl.pos = p; sl.state = si; sl.lo = c.lo; sl.hi = c.hi; sl.nclu = c.nclu; sl.th = c.th; sl.expect = expect; sl.pred_ratio = pred_ratio;
     // (ids only grow, per slot too: the kernels give up when their slot's word has reached their id, so an abort also
     // reaches a launch that was still queued behind another aborted one when the word moved on)
     sl.launch_id = h->next_launch_id++;
@@ -2613,9 +2617,9 @@ static int spec_pump(ipc_engine* h)
         const bool stale = aborted || p < h->spec_head || sl.state != spec_state_at(h, p);
         if (h->spec_log) {
             const auto us = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t - h->spec_log_t0).count(); };
-            fprintf(h->spec_log, "solve,%.0f,%.0f,%d,%d,%d,%d,%d,%d,%d,%d,%.0f\n", us(sl.t_launch), us(std::chrono::steady_clock::now()), p, sl.cand, sl.expect,
+            fprintf(h->spec_log, "solve,%.0f,%.0f,%d,%d,%d,%d,%d,%d,%d,%d,%.0f,%.4g\n", us(sl.t_launch), us(std::chrono::steady_clock::now()), p, sl.cand, sl.expect,
                     h->spec_states[sl.state].pos, stale ? (aborted ? 2 : 1) : 0, !(o.max_chi2 > sl.th) ? 1 : 0, o.iterations, sl.nclu,
-                    h->dim == 3 ? sl.s3->device_us() : sl.s2->device_us());
+                    h->dim == 3 ? sl.s3->device_us() : sl.s2->device_us(), sl.pred_ratio);
         }
         sl.cand = -1;
         if (stale) { ++h->spec_wasted; continue; }
@@ -2678,6 +2682,7 @@ static int spec_pump(ipc_engine* h)
                                                        // leaves their order open, src/utils.cpp:379-389), so they are not "behind" it
     int behind = 0;                                    // solves in flight behind it
     int chain_out = 0;                                 // (first scan) expected accepts in flight, gate and hedges
+    int toss_out = 0;                                  // (first scan) of them the coin tosses (uncertain_from)
     const int hedge = h->spec_hedge >= 0 ? h->spec_hedge : (h->st_acc_n >= 8 && h->st_acc_s >= 3e-3 * (double)h->st_acc_n ? 1 : 0);
     for (int lp = h->spec_head; lp < end; ++lp) {
         if (h->spec_res[lp].valid) continue;
@@ -2699,12 +2704,15 @@ static int spec_pump(ipc_engine* h)
         if (at >= 0) {
             if (gated) behind += !tied;
             else if (pa && std::chrono::duration<double, std::milli>(now - h->slots[at].t_launch).count() < release_ms) { gated = true; gate_hi = h->h_hi[cand_lp]; }
-            if (pa_only && gated && pa && ++chain_out > hedge) break;   // (the chain is running)
+            if (pa_only && gated && pa) {                // (the chain is running)
+                if (h->uncertain_from > 0.0 && h->slots[at].pred_ratio > h->uncertain_from) { if (++toss_out > 2) break; }
+                else if (++chain_out > hedge) break;
+            }
             continue;
         }
         if (pa_only && !pa) continue;
         if (q < 0 || running >= target) { why = -1; break; }
-        if (gated && !tied && behind >= h->spec_behind && !(pa_only && hedge > 0)) { why = 0; break; }     // (a hedge is not one of the `behind`)
+        if (gated && !tied && behind >= h->spec_behind && !(pa_only && (hedge > 0 || toss_out > 0))) { why = 0; break; }     // (a hedge is not one of the `behind`)
         // every workgroup of every solve on the GPU must be resident (they meet at grid barriers) and one workgroup fills
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
@@ -2728,7 +2736,8 @@ static int spec_pump(ipc_engine* h)
         if (helpers < std::min(8, h->helper_limit) && running > 0) { why = 2; break; }        // (wait for a solve to leave)
         const int tip = spec_state_at(h, lp);
         if (!PersistSolver<PersistSe2>::fits(h->V, (int)h->spec_states[tip].cns.size() + 1)) { why = 3; break; }
-        if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject, (cur_pred || file_pred) ? (pa ? 1 : 0) : -1)) return rc;
+        if (int rc = spec_launch(h, q, lp, std::max(0, helpers), expect_reject, (cur_pred || file_pred) ? (pa ? 1 : 0) : -1,
+                                  cur_pred && cand_lp < cur_n ? cur_pred[cand_lp] / h->prm.slow_reject_th : -1.0)) return rc;
         if (gated) behind += !tied;
         else if (pa) { gated = true; gate_hi = h->h_hi[cand_lp]; }
         if (pa_only) break;
