@@ -2758,6 +2758,7 @@ static int spec_reset(ipc_engine* h)
 {
     for (size_t q = 0; q < h->slots.size(); ++q) spec_abort_slot(h, (int)q);
     for (auto& sl : h->slots) HIPCHK(hipStreamSynchronize(sl.st));
+    if (h->pred_stream) HIPCHK(hipStreamSynchronize(h->pred_stream));      // (the prediction kernels read the candidates and the states' poses)
     for (auto& R : h->spec_res) R.valid = false;
     for (int t : h->tent) h->spec_states[t].live = false;
     h->tent.clear();
