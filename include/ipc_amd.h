@@ -256,6 +256,16 @@ int ipc_add_to_consensus(ipc_engine_t* h, int k);
 /* Current pose estimates (the g2o vertex estimates the reference mutates). */
 int ipc_current_poses(ipc_engine_t* h, double* poses_out);
 
+/* Resume the loop of src/simulation.cpp:34-47 from a saved state.  Everything IPC::agreementCheck reads and writes is the
+ * vertex estimates of the borrowed optimizer and _max_consensus_set (include/ipc/consensus.hpp:23-32), so a pair
+ * (ipc_current_poses, ipc_consensus_set) taken at any point of a run, handed back here, continues that run -- on this engine
+ * or on another engine of the same graph and candidate list (round 6: how the tests put the engine into late states of
+ * BASELINE configs[3] / [4] whose checks the CPU oracle was given hours for).  poses as ipc_current_poses() returns them
+ * (SE3: bit for bit the state; SE2: cos / sin of theta are recomputed, a rounding-level difference); cns = candidate FILE
+ * indices in set order; resume_position = how many candidates of the processing order (ipc_candidate_order) count as
+ * already handed out -- it only tells the look-ahead pipeline where the caller will continue, any value 0..N is correct. */
+int ipc_incremental_set_state(ipc_engine_t* h, const double* poses, const int* cns, int n_cns, int resume_position);
+
 /* Final map (src/simulation.cpp:50-65): open-loop guess, odometry information back to
  * (info * s) / s, every candidate with accepted[k] != 0, optimize(iterations) with vertex 0
  * fixed (the harness uses 1000).  poses_out and info may be NULL. */
@@ -275,13 +285,15 @@ int ipc_debug_dense_solve(int n, const double* system, int mode, int workgroups,
  * sparse solver, src/utils.cpp:104-105).  system: nb + m - 1 columns of W + m doubles -- column j holds rows j .. j+W-1
  * (band; W >= 64) and then the m dense rows (the wide loops' unknowns, right-hand side last); nb band columns. */
 int ipc_debug_band_solve(int nb, int m, int W, const double* system, int workgroups, double* x_out, int* info_out);
-/* The band structure found for a set of loops (host code, no GPU): a / b = first / last vertex per loop, d = 3 (SE2) or
- * 6 (SE3) unknowns per loop, min_n = smallest system that is banded at all (0: always).  use_out 0: dense solver. */
 /* computeIndependentSubgraph (src/consensus.cpp:124-171) on bare intervals (host code, no GPU): the accepted edges -- positions
  * into lo / hi -- a candidate [klo, khi] absorbs, and the hull.  sweep 0: the reference's fixed-point re-scan; sweep 1: one pass
  * over the intervals sorted by first vertex (what the engine uses for sets of 512 and more).  Same set, same hull. */
 int ipc_debug_absorbed_edges(int klo, int khi, int n, const int* lo, const int* hi, int sweep, int* members_out, int* n_members_out,
                              int* lo_out, int* hi_out);
+/* The band structure found for a set of loops (host code, no GPU): a / b = first / last vertex per loop, d = 3 (SE2) or
+ * 6 (SE3) unknowns per loop, min_n = smallest system that is banded at all (0: always).  *use_out = 0: the dense solver
+ * takes the cluster and nlb_out / bwb_out / order_out are NOT written; *use_out = 1: nlb_out = loops in the band,
+ * bwb_out = half-bandwidth in blocks, order_out[nl] = the loops in band order, the border's wide loops last. */
 int ipc_debug_band_plan(int d, int nl, const int* a, const int* b, int min_n, int* use_out, int* nlb_out, int* bwb_out,
                         int* order_out);
 

@@ -30,7 +30,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_incremental_prepare", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
-    "ipc_debug_dense_solve", "ipc_debug_band_solve", "ipc_debug_band_plan", "ipc_debug_absorbed_edges", "ipc_append_candidate", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
+    "ipc_debug_dense_solve", "ipc_debug_band_solve", "ipc_debug_band_plan", "ipc_debug_absorbed_edges", "ipc_append_candidate", "ipc_incremental_set_state", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.ipc_remove_from_consensus.argtypes = [vp, ip, C.POINTER(ip)]
     lib.ipc_add_to_consensus.argtypes = [vp, ip]
     lib.ipc_current_poses.argtypes = [vp, vp]
+    lib.ipc_incremental_set_state.argtypes = [vp, vp, vp, ip, ip]
     lib.ipc_final_optimize.argtypes = [vp, vp, ip, vp, C.POINTER(CheckInfo)]
     lib.ipc_debug_dense_solve.argtypes = [ip, vp, ip, ip, vp, C.POINTER(ip)]
     lib.ipc_debug_band_solve.argtypes = [ip, ip, ip, vp, ip, vp, C.POINTER(ip)]

@@ -152,6 +152,15 @@ class IPC:
         capi.check(self.lib.ipc_current_poses(self.h, _p(out)))
         return out
 
+    def set_state(self, poses, consensus, resume_position=0):
+        """Resume the agreementCheck loop from a saved (current_poses(), getMaxConsensusSet()) pair
+        (ipc_incremental_set_state; the two are all the state of reference include/ipc/consensus.hpp:23-32)."""
+        poses = _d(poses)
+        assert poses.shape == (self.graph.V, 3 if self.dim == 2 else 12)
+        cns = np.ascontiguousarray(consensus, dtype=np.int32)
+        capi.check(self.lib.ipc_incremental_set_state(self.h, _p(poses), _p(cns), int(cns.shape[0]), int(resume_position)))
+        self._max_consensus_set = cns.copy()
+
     def final_optimize(self, accepted, iterations=1000):
         """The harness's final map (reference src/simulation.cpp:50-65): returns (poses [V,3] or
         [V,12] (R row-major, t), CheckInfo with chi2_total)."""

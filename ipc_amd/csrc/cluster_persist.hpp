@@ -1113,6 +1113,12 @@ public:
         }
         last_split_ = split_s >= 0;
         const size_t band_doubles = split_s >= 0 ? 2 * (band_.doubles() + band2_.doubles()) : 2 * band_.doubles();
+        // The factorisation and the back substitution index one system with 32-bit products (j * ld + i, BandLayout::at32):
+        // a system of 2^31 doubles and more (16 GB; ~11 000 SE3 loops in ONE non-banded cluster) would wrap silently.
+        {
+            const size_t one = plan.use ? std::max(band_.doubles(), split_s >= 0 ? band2_.doubles() : (size_t)0) : ((size_t)n + 1) * n;
+            if (one >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+        }
         IPC_CL_CHK(ensure(L, nl, plan.use ? band_doubles : 2 * ((size_t)n + 1) * n));
         const int ld = L + 2;
         Dev& D = dev_;

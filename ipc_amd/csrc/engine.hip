@@ -1433,7 +1433,7 @@ __device__ __forceinline__ int slot_of_cell(const unsigned* slot_off, int nslots
 // lit_idx at the slot's own offset: a slot has room for all of its cells), counted per slot in recount[0 .. nslots).
 __global__ void k_collect_failed(int ncells, const int4* meta, const double* chi, const int2* cells, double fast_th,
                                  double slow_th, double band, bool want_failed, int cap, int* list, int* recount,
-                                 const unsigned* slot_off, int nslots, int2* lit_cells, int* lit_idx)
+                                 const unsigned* slot_off, int nslots, int2* lit_cells, int* lit_idx, int long_bin)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
@@ -1449,6 +1449,13 @@ __global__ void k_collect_failed(int ncells, const int4* meta, const double* chi
         if (q < cap) list[q] = c;
     } else if (border) {
         const int sl = slot_of_cell(slot_off, nslots, c);
+        if (sl == long_bin || sl == (nslots >> 1) + long_bin) {
+            // a chain beyond every cell kernel (solve_long_cells): no kernel re-solves that slot -- onto the host list, where
+            // the cluster solver runs it again with g2o's literal loop (resolve_failed_cells tells the two kinds apart by flags & 2)
+            const int q = atomicAdd(recount + nslots, 1);
+            if (q < cap) list[q] = c;
+            return;
+        }
         const int q = atomicAdd(recount + sl, 1);
         lit_cells[slot_off[sl] + q] = cc;
         lit_idx[slot_off[sl] + q] = c;
@@ -1532,12 +1539,30 @@ static int resolve_failed_cells(ipc_engine* h, int n)
         int iters = nl == 1 ? h->prm.fast_reject_iter_base : h->prm.slow_reject_iter_base;
         if ((hi - lo) + nl > 100) iters *= 5;                                  // consensus_utils.cpp:12-13
         ClusterOut o;
-        HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, true));    // (damping: host-driven solver)
+        int4 was;
+        HIPCHK(hipMemcpy(&was, h->d_meta + idx[q], sizeof(int4), hipMemcpyDeviceToHost));
+        if (was.z & 2) {
+            HIPCHK(cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o, true));    // (damping: host-driven solver)
+            ++h->last_lm_cells;
+        } else {
+            // a borderline cell of the long slots (k_collect_failed): g2o's literal trial loop, convergence test off
+            const double te = h->term_eps;
+            auto set_eps = [&](double v) {
+                if (h->cluster) h->cluster->term_eps = v;
+                if (h->cluster3) h->cluster3->term_eps = v;
+                if (h->persist2) h->persist2->term_eps = v;
+                if (h->persist3) h->persist3->term_eps = v;
+            };
+            set_eps(0.0);
+            const hipError_t e = cluster_solve(h, h->d_chain, h->d_open, lo, hi, members, iters, o);
+            set_eps(te);
+            HIPCHK(e);
+            ++h->last_literal_cells;
+        }
         const int4 meta = make_int4(o.iterations, o.tries, o.flags, o.evals);
         HIPCHK(hipMemcpy(h->d_chi + idx[q], &o.max_chi2, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_chitot + idx[q], &o.chi2_total, sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_meta + idx[q], &meta, sizeof(int4), hipMemcpyHostToDevice));
-        ++h->last_lm_cells;
     }
     HIPCHK(hipStreamSynchronize(nullptr));                     // (NULL-stream copies are not ordered against the engine's non-blocking streams: copy_d2d_now)
     return IPC_OK;
@@ -1610,7 +1635,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
             HIPCHK(hipMalloc(&h->d_chitot, sizeof(double) * h->cells_cap));
             HIPCHK(hipMalloc(&h->d_meta, sizeof(int4) * h->cells_cap));
             HIPCHK(hipMalloc(&h->d_lit_cells, sizeof(int2) * h->cells_cap));
-            HIPCHK(hipMalloc(&h->d_lit_idx, sizeof(int) * h->cells_cap));
+            HIPCHK(hipMalloc(&h->d_lit_idx, sizeof(int) * (h->cells_cap + 1)));      // (+ 1: k_slow_flags / k_scan_int write and scan total + 1 entries)
             HIPCHK(hipMalloc(&h->d_lit_chi, sizeof(double) * h->cells_cap));
             HIPCHK(hipMalloc(&h->d_lit_chitot, sizeof(double) * h->cells_cap));
             HIPCHK(hipMalloc(&h->d_lit_meta, sizeof(int4) * h->cells_cap));
@@ -1718,7 +1743,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
         HIPCHK(hipMemsetAsync(h->d_recount, 0, sizeof(int) * (NS + 1), st));
         hipLaunchKernelGGL(k_collect_failed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)total, (const int4*)h->d_meta,
                            (const double*)h->d_chi, (const int2*)h->d_cells, h->prm.fast_reject_th, h->prm.slow_reject_th, band,
-                           h->lm_retry, h->failed_cap, h->d_failed, h->d_recount, (const unsigned*)h->d_slot_off, NS, h->d_lit_cells, h->d_lit_idx);
+                           h->lm_retry, h->failed_cap, h->d_failed, h->d_recount, (const unsigned*)h->d_slot_off, NS, h->d_lit_cells, h->d_lit_idx, nb);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h->h_recount, h->d_recount, sizeof(int) * (NS + 1), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1743,7 +1768,7 @@ static int solve_rows_impl(ipc_engine* h, int rank, int world, uint64_t* d_upper
                                (const unsigned*)h->d_slot_off, NS, (const int*)h->d_recount, (const int*)h->d_lit_idx, (const double*)h->d_lit_chi,
                                (const double*)h->d_lit_chitot, (const int4*)h->d_lit_meta, h->d_chi, h->d_chitot, h->d_meta);
             HIPCHK(hipGetLastError());
-            h->last_literal_cells = n_lit;
+            h->last_literal_cells += n_lit;
         }
         if (h->h_recount[NS]) {
             if (int rc = resolve_failed_cells(h, h->h_recount[NS])) return rc;
@@ -2132,6 +2157,47 @@ extern "C" int ipc_incremental_reset(ipc_engine_t* h)
     std::fill(h->handed.begin(), h->handed.end(), 0);
     h->porder = h->order;
     for (int q = 0; q < h->N; ++q) h->ppos[h->porder[q]] = q;
+    return IPC_OK;
+}
+
+// Resume the faithful loop from a saved state: the g2o vertex estimates and _max_consensus_set are ALL the state
+// IPC::agreementCheck reads and writes (include/ipc/consensus.hpp:23-32), so (ipc_current_poses, ipc_consensus_set) taken
+// at any point of a run and handed back here continue that run -- on this engine or another one of the same graph.
+extern "C" int ipc_incremental_set_state(ipc_engine_t* h, const double* poses, const int* cns, int n_cns, int resume_position)
+{
+    if (!h || !poses || n_cns < 0 || (n_cns > 0 && !cns)) return fail(IPC_ERR_ARG, "ipc_incremental_set_state: bad argument");
+    if (resume_position < 0 || resume_position > h->N) return fail(IPC_ERR_ARG, "ipc_incremental_set_state: resume position %d of %d", resume_position, h->N);
+    for (int q = 0; q < n_cns; ++q)
+        if (cns[q] < 0 || cns[q] >= h->N) return fail(IPC_ERR_ARG, "ipc_incremental_set_state: member %d of %d candidates", cns[q], h->N);
+    if (int rc = ensure_incremental(h, "ipc_incremental_set_state")) return rc;
+    if (int rc = spec_quiesce(h, true)) return rc;
+    const size_t V = (size_t)h->V;
+    const int nf = h->dim == 2 ? 3 : 12;
+    std::vector<double> tmp((size_t)nf * V);
+    for (size_t i = 0; i < V; ++i)
+        for (int f = 0; f < nf; ++f) tmp[(size_t)f * V + i] = poses[(size_t)nf * i + f];
+    if (h->dim == 3) {
+        HIPCHK(hipMemcpyAsync(h->d_cur, tmp.data(), sizeof(double) * 12 * V, hipMemcpyHostToDevice, h->own_stream));
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+    } else {
+        double* d_tmp = nullptr;                           // [3][V] -> [5][V] (cos, sin as every pose of the engine carries them)
+        HIPCHK(hipMalloc(&d_tmp, sizeof(double) * 3 * V));
+        HIPCHK(hipMemcpyAsync(d_tmp, tmp.data(), sizeof(double) * 3 * V, hipMemcpyHostToDevice, h->own_stream));
+        hipLaunchKernelGGL(k_pose5_init, dim3((h->V + 255) / 256), dim3(256), 0, h->own_stream, h->V, d_tmp, h->d_cur);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->own_stream));
+        HIPCHK(hipFree(d_tmp));
+    }
+    h->cns.assign(cns, cns + n_cns);
+    h->cns_dups = false;
+    {
+        std::vector<int> s(h->cns);
+        std::sort(s.begin(), s.end());
+        h->cns_dups = std::adjacent_find(s.begin(), s.end()) != s.end();
+    }
+    // the pipeline's prediction of the caller's order: the first resume_position candidates count as handed out
+    h->porder = h->order;
+    for (int q = 0; q < h->N; ++q) { h->ppos[h->porder[q]] = q; h->handed[h->porder[q]] = q < resume_position ? 1 : 0; }
     return IPC_OK;
 }
 

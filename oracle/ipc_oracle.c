@@ -490,6 +490,9 @@ static void sub_multiply_hessian(sub_t *s, double *dest, const double *src)
     }
 }
 
+static int g_wide_dots = 0;
+void oracle_set_wide_dots(int on) { g_wide_dots = on; }
+
 /* LinearSolverEigen::solve: LL^T of H (+lambda on the diagonal when asked), fails on a
  * non-positive pivot like SimplicialLLT; then two triangular solves. */
 static int sub_solve(sub_t *s, double lambda, int add_lambda)
@@ -506,6 +509,23 @@ static int sub_solve(sub_t *s, double lambda, int add_lambda)
             int fj = s->first[j];
             int k0 = fi > fj ? fi : fj;
             double sum = ri[j - fi];
+            if (g_wide_dots && j - k0 >= 16) {
+                /* (oracle_set_wide_dots: the same envelope factorisation, the dot product over the shared columns
+                 * accumulated in eight independent partial sums instead of one serial chain -- rounding-level
+                 * different, several times faster; for the late states of C4 / C5, whose systems have 15 000 to
+                 * 180 000 unknowns, tests/golden/make_late_state_golden.py) */
+                const double *a = ri + (k0 - fi), *b = rj + (k0 - fj);
+                int len = j - k0, k = 0;
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+                for (; k + 8 <= len; k += 8) {
+                    s0 += a[k] * b[k];         s1 += a[k + 1] * b[k + 1];
+                    s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3];
+                    s4 += a[k + 4] * b[k + 4]; s5 += a[k + 5] * b[k + 5];
+                    s6 += a[k + 6] * b[k + 6]; s7 += a[k + 7] * b[k + 7];
+                }
+                for (; k < len; ++k) s0 += a[k] * b[k];
+                sum -= ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+            } else
             for (int k = k0; k < j; ++k) sum -= ri[k - fi] * rj[k - fj];
             if (j < i) ri[j - fi] = sum / rj[j - fj];
             else {
@@ -916,6 +936,17 @@ int oracle_ipc_consensus_size(const oracle_ipc_t *h) { return h->ncns; }
 void oracle_ipc_consensus(const oracle_ipc_t *h, int *out) { memcpy(out, h->cns, sizeof(int) * (size_t)h->ncns); }
 void oracle_ipc_poses(const oracle_ipc_t *h, double *out)
 { memcpy(out, h->poses, sizeof(double) * (size_t)h->V * pose_size(h->dim)); }
+
+/* The whole state of the reference's IPC object (include/ipc/consensus.hpp:23-32: the vertex estimates of the borrowed
+ * optimizer and _max_consensus_set) set from outside: a run continued from a saved state, e.g. one the GPU engine dumped
+ * late in a run the oracle cannot reach on its own in days (tests/golden/make_late_state_golden.py). */
+void oracle_ipc_set_state(oracle_ipc_t *h, const double *poses, const int *cns, int ncns)
+{
+    memcpy(h->poses, poses, sizeof(double) * (size_t)h->V * pose_size(h->dim));
+    h->cns = (int *)realloc(h->cns, sizeof(int) * ((size_t)ncns + (size_t)h->N + 1));   /* (room for every later accept) */
+    memcpy(h->cns, cns, sizeof(int) * (size_t)ncns);
+    h->ncns = ncns;
+}
 
 /* agreementCheck (consensus.cpp:43-75) for candidate k; returns 1 accepted / 0 rejected.
  * info_out (may be NULL): [lo, hi, n_cluster_loops, iterations]; maxchi2_out may be NULL. */

@@ -71,6 +71,12 @@ def info_size(dim):
     return 6 if dim == 2 else 21
 
 
+def set_wide_dots(on):
+    """Envelope factorisation with eight partial sums per dot product (rounding-level different, several times faster);
+    off by default -- every committed fixture except the late-state ones was made with the serial sums."""
+    lib().oracle_set_wide_dots(int(bool(on)))
+
+
 def normalize_theta(t):
     return lib().oracle_normalize_theta(float(t))
 
@@ -233,6 +239,13 @@ class IncrementalIPC:
         r = lib().oracle_ipc_agreement_check(self.h, int(k), _p(info), C.byref(mx))
         return bool(r), dict(lo=int(info[0]), hi=int(info[1]), cluster=int(info[2]),
                              iterations=int(info[3]), max_chi2=mx.value)
+
+    def set_state(self, poses, consensus):
+        """Continue from a saved state: vertex estimates [V, 3 | 12] + consensus set (candidate indices in set order)."""
+        poses = _d(poses)
+        assert poses.shape == (self.V, pose_size(self.dim))
+        cns = _i(consensus)
+        lib().oracle_ipc_set_state(self.h, _p(poses), _p(cns), int(cns.shape[0]))
 
     def consensus(self):
         n = lib().oracle_ipc_consensus_size(self.h)

@@ -1,0 +1,186 @@
+"""The WHOLE faithful runs of BASELINE configs[3] (C4) and configs[4] (C5) under the driver, and their late part under the
+oracle.
+
+The reference loops IPC::agreementCheck over every candidate (src/simulation.cpp:34-47 -> src/consensus.cpp:43-75).  The
+CPU oracle's own run reaches candidate 1 205 of C4's 4 450 and 3 239 of C5's 25 000 in 45 min each
+(tests/golden/c{4,5}_incremental_expected.npz); behind that the clusters grow to 1 992 / 3 328 accepted loops -- the
+banded, split solver of cluster_band.hpp -- and until round 6 nothing but the engine itself had looked at those checks.
+
+  * full runs: every candidate through the look-ahead pipeline; decisions, cluster spans and sizes equal to the committed
+    records of the run the late states were taken from, accepted counts, the final consensus set; a late window of the run
+    repeated one check at a time (IPC_SPEC_WINDOW=1) from the pipeline run's own state: bit for bit the same records;
+    the consensus set a fixed point of computeIndependentSubgraph's rule (src/consensus.cpp:124-171) in both of its forms;
+  * STATE-INJECTED ORACLE CHECKS: the state of the reference's IPC object is the vertex estimates and _max_consensus_set
+    (include/ipc/consensus.hpp:23-32).  tools/late_state_dump.py took that pair in front of late checks of the GPU runs;
+    tests/golden/make_late_state_golden.py put the oracle into each state and let it check the candidate (minutes to hours
+    per position in the build container); here the engine is put into the same states (ipc_incremental_set_state) and must
+    take the oracle's decision, find the oracle's cluster (lo, hi, size) and end on its max edge chi2 within 1e-5.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _engine(g, cfg, **env):
+    from ipc_amd.consensus import IPC
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return IPC(g, cfg, device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _window_to_poses(dim, w):
+    """tests/golden/make_late_state_golden.py::window_to_poses (the oracle was given exactly these numbers)."""
+    if dim == 2:
+        return w
+    q = w[:, :4] / np.linalg.norm(w[:, :4], axis=1, keepdims=True)
+    qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                  2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                  2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)], axis=1)
+    return np.concatenate([R, w[:, 4:7]], axis=1)
+
+
+def _load(tag):
+    import bench
+    fx = np.load(os.path.join(GOLD, "%s_late_states.npz" % tag))
+    g, cfg, _ = bench.build_workload(str(fx["workload"]))
+    assert int(np.asarray(g.loop_ids, dtype=np.int64).sum()) == int(fx["loop_ids_checksum"]), "workload changed"
+    assert abs(float(np.asarray(g.loop_meas).sum()) - float(fx["meas_checksum"])) < 1e-9, "workload changed"
+    return fx, g, cfg
+
+
+def _record(ok, info):
+    return (ok, info.lo, info.hi, info.n_cluster_loops, info.iterations, info.tries, info.flags, info.max_chi2, info.chi2_total,
+            info.chi2_initial)
+
+
+def _bitwise(a, b):
+    return a[:7] == b[:7] and all(np.float64(x).tobytes() == np.float64(y).tobytes() or (x != x and y != y) for x, y in zip(a[7:], b[7:]))
+
+
+def _late_states(tag, min_positions, min_cluster):
+    fx, g, cfg = _load(tag)
+    n = len(fx["position"])
+    assert n >= min_positions
+    assert int(fx["cluster"].max()) >= min_cluster
+    assert fx["decision"].any() and not fx["decision"].all()                # accepts AND rejects
+    eng = _engine(g, cfg, IPC_SPEC_WINDOW=1)
+    order = eng.candidate_order()
+    open_loop = eng.initial_poses()
+    worst, differ = 0.0, []
+    for i in range(n):
+        q, k = int(fx["position"][i]), int(fx["candidate"][i])
+        assert int(order[q]) == k
+        lo, hi = int(fx["lo"][i]), int(fx["hi"][i])
+        poses = open_loop.copy()
+        poses[lo:hi + 1] = _window_to_poses(g.dim, fx["window"][fx["window_off"][i]:fx["window_off"][i + 1]])
+        eng.set_state(poses, fx["cns"][fx["cns_off"][i]:fx["cns_off"][i + 1]], q)
+        ok, info = eng.agreementCheck(k, with_info=True)
+        assert (info.lo, info.hi, info.n_cluster_loops) == (lo, hi, int(fx["cluster"][i])), (i, q, k)
+        ref = float(fx["max_chi2"][i])
+        err = abs(info.max_chi2 - ref) / max(abs(ref), 1e-12)
+        worst = max(worst, err)
+        if ok != bool(fx["decision"][i]) or err > REL:
+            differ.append((i, q, k, ok, bool(fx["decision"][i]), info.max_chi2, ref, info.iterations, int(fx["iterations"][i]), str(fx["reason"][i])))
+    assert not differ, differ
+    print("\n[%s late states] %d positions (clusters of %d ... %d loops, %d accepts / %d rejects), worst relative chi2 difference "
+          "from the oracle %.2e" % (tag, n, int(fx["cluster"].min()), int(fx["cluster"].max()), int(fx["decision"].sum()),
+                                    int(n - fx["decision"].sum()), worst))
+    eng.close()
+
+
+def test_c4_late_states_against_the_oracle():
+    """BASELINE configs[3]: >= 16 late positions, clusters of >= 1 000 loops, the largest cluster of the run included."""
+    _late_states("c4", 16, 1900)
+
+
+def test_c5_late_states_against_the_oracle():
+    """BASELINE configs[4]: >= 8 late positions (chains of up to 30 000 poses = 180 000 unknowns in the oracle's system)."""
+    _late_states("c5", 8, 3000)
+
+
+def _full_run(tag, window_at, window_len):
+    from ipc_amd import capi
+    fx, g, cfg = _load(tag)
+    eng = _engine(g, cfg)
+    order = eng.candidate_order()
+    n = len(order)
+    assert n == len(fx["run_decision"])
+    eng.reset()
+    recs = []
+    saved = None
+    for q in range(n):
+        if q == window_at:
+            saved = (eng.current_poses(), eng.getMaxConsensusSet().copy())
+        ok, info = eng.agreementCheck(int(order[q]), with_info=True)
+        recs.append(_record(ok, info))
+    dec = np.array([r[0] for r in recs], dtype=np.uint8)
+    clu = np.array([r[3] for r in recs])
+    # the run the oracle-checked states were taken from: same decisions, same clusters, same chi2 to rounding
+    assert np.array_equal(dec, fx["run_decision"]), np.nonzero(dec != fx["run_decision"])[0][:10]
+    assert np.array_equal(clu, fx["run_cluster"])
+    assert np.array_equal(np.array([r[1] for r in recs]), fx["run_lo"]) and np.array_equal(np.array([r[2] for r in recs]), fx["run_hi"])
+    mx = np.array([r[7] for r in recs])
+    both = np.isfinite(mx) & np.isfinite(fx["run_max_chi2"])
+    assert np.abs(mx[both] - fx["run_max_chi2"][both]).max() <= 1e-6 * np.maximum(np.abs(fx["run_max_chi2"][both]), 1e-9).max()
+    cns = eng.getMaxConsensusSet()
+    assert np.array_equal(cns, fx["run_final_consensus"])
+    assert np.array_equal(cns, order[dec[np.arange(n)] == 1])               # the accepted candidates, in processing order
+    # at the oracle-checked positions the live run agrees with the ORACLE as well
+    for i, q in enumerate(fx["position"]):
+        r = recs[int(q)]
+        assert r[0] == bool(fx["decision"][i]) and (r[1], r[2], r[3]) == (int(fx["lo"][i]), int(fx["hi"][i]), int(fx["cluster"][i]))
+        assert abs(r[7] - float(fx["max_chi2"][i])) <= REL * max(abs(float(fx["max_chi2"][i])), 1e-12)
+    # the consensus set is a fixed point of computeIndependentSubgraph's rule, in the reference's re-scan form and in the
+    # engine's one-sweep form: for a handful of members, both find the same cluster inside the final set
+    lib = capi.load()
+    ids = np.asarray(g.loop_ids, dtype=np.int32).reshape(-1, 2)
+    lo_all = np.ascontiguousarray(ids[cns].min(axis=1).astype(np.int32))
+    hi_all = np.ascontiguousarray(ids[cns].max(axis=1).astype(np.int32))
+    for m in np.linspace(0, len(cns) - 1, 6).astype(int):
+        outs = []
+        for sweep in (0, 1):
+            mem = np.zeros(len(cns), dtype=np.int32)
+            nm, olo, ohi = C.c_int(0), C.c_int(0), C.c_int(0)
+            capi.check(lib.ipc_debug_absorbed_edges(int(lo_all[m]), int(hi_all[m]), len(cns), lo_all.ctypes.data_as(C.c_void_p),
+                                                    hi_all.ctypes.data_as(C.c_void_p), sweep, mem.ctypes.data_as(C.c_void_p),
+                                                    C.byref(nm), C.byref(olo), C.byref(ohi)))
+            outs.append((set(mem[:nm.value].tolist()), olo.value, ohi.value))
+        assert outs[0] == outs[1] and m in outs[0][0]
+    # a late window again, one check at a time, from the pipeline run's own state: bit for bit the pipeline's records
+    e1 = _engine(g, cfg, IPC_SPEC_WINDOW=1)
+    e1.set_state(saved[0], saved[1], window_at)
+    for q in range(window_at, window_at + window_len):
+        ok, info = e1.agreementCheck(int(order[q]), with_info=True)
+        assert _bitwise(_record(ok, info), recs[q]), (q, _record(ok, info), recs[q])
+    e1.close()
+    eng.close()
+    return int(dec.sum()), int(clu.max())
+
+
+def test_c4_full_faithful_run():
+    """All 4 450 candidates of BASELINE configs[3] (58 s in round 5)."""
+    acc, big = _full_run("c4", 3900, 48)
+    assert big >= 1900 and acc >= 1900
+    print("\n[C4 full run] %d accepted, largest cluster %d loops" % (acc, big))
+
+
+def test_c5_full_faithful_run():
+    """All 25 000 candidates of BASELINE configs[4] (144 s in round 5)."""
+    acc, big = _full_run("c5", 23000, 120)
+    assert big >= 3000 and acc >= 4500
+    print("\n[C5 full run] %d accepted, largest cluster %d loops" % (acc, big))

@@ -175,6 +175,72 @@ def test_chain_beyond_every_cell_kernel_goes_through_the_cluster_fallback(oracle
     assert np.array_equal(acc, O.set_max(C, O.candidate_order(g.loop_ids)))
 
 
+def test_borderline_cells_of_chains_beyond_every_cell_kernel_are_solved_again_literally(oracle):
+    """a cell whose chain is longer than the largest cell kernel is solved by the cluster solver
+    (solve_long_cells); when its chi2 ends inside the borderline band no cell kernel can re-solve it, and the scatter of the
+    literal results used to copy whatever the (never written) literal buffers of that slot held.  Now such a cell goes
+    through the cluster solver again with g2o's literal loop.  A full-span loop on an 8000-pose trajectory whose offset is
+    scaled so that its own chi2 sits at ~0.9 of the threshold, band opened to 0.5: same decisions and chi2 as a run with
+    the convergence test off everywhere, and as the oracle."""
+    from ipc_amd import synth
+    O = oracle
+    g0 = synth.chain3d(seed=8, V=8000, n_loops=6, max_span=150)
+    poses = O.propagate(3, g0.odom_meas)
+    a, b = 5, 7995
+    Ra, ta = poses[a][:9].reshape(3, 3), poses[a][9:]
+    Rb, tb = poses[b][:9].reshape(3, 3), poses[b][9:]
+    Rab, tab = Ra.T @ Rb, Ra.T @ (tb - ta)
+    q = synth._R_to_quat(Rab)
+
+    def graph(delta):
+        full = np.concatenate([tab + np.array([delta, 0.0, 0.0]), q])
+        return synth.PoseGraph(3, g0.vertices, g0.odom_meas, g0.odom_info, np.vstack([g0.loop_ids, [[a, b]]]).astype(np.int32),
+                               np.vstack([g0.loop_meas, full]), np.vstack([g0.loop_info, g0.loop_info[:1]]), dict(g0.meta))
+
+    th = 6.251
+
+    def own_chi2(g):
+        k = g.N - 1
+        return O.solve_cell(3, g.odom_meas, g.odom_info, 50.0, poses, a, b, g.loop_ids[k:k + 1], g.loop_meas[k:k + 1],
+                            g.loop_info[k:k + 1], 50)["max_chi2"]
+
+    d0 = 1.0
+    c0 = own_chi2(graph(d0))
+    delta = d0 * np.sqrt(0.9 * th / c0)                         # (chi2 grows with the square of the offset)
+    g = graph(delta)
+    ref = own_chi2(g)
+    assert 0.6 * th < ref < 1.4 * th, ref
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            eng, cfg = _engine(g, s_factor=50.0, slow_reject_th=th)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        bits, acc = eng.run()
+        return eng.cell_info(), eng.solve_report(), acc
+
+    cells_b, rep_b, acc_b = run(dict(IPC_BORDERLINE_BAND=0.5))
+    cells_l, rep_l, acc_l = run(dict(IPC_TERMINATE_EPS=0))
+    L = cells_b["hi"] - cells_b["lo"]
+    assert rep_b["long_cells"] >= 1 and rep_b["literal_cells"] >= 1
+    assert np.array_equal(cells_b["i"], cells_l["i"]) and np.array_equal(cells_b["j"], cells_l["j"])
+    assert np.array_equal(acc_b, acc_l)
+    long = np.nonzero(L > 4096)[0]
+    k = g.N - 1
+    own = [c for c in long if cells_b["i"][c] == k and cells_b["j"][c] == k]
+    assert len(own) == 1
+    assert abs(cells_b["max_chi2"][own[0]] - ref) <= 1e-5 * ref, (cells_b["max_chi2"][own[0]], ref)
+    for c in long:
+        x, y = cells_b["max_chi2"][c], cells_l["max_chi2"][c]
+        assert (x > th) == (y > th) and abs(x - y) <= 1e-6 * max(abs(y), 1e-9), (cells_b[c], cells_l[c])
+
+
 def test_team_kernels_are_deterministic_when_the_last_wave_is_nearly_empty(oracle):
     """C4m (sphere2500-like, 445 candidates, chains to 2493 poses): two engines, two runs each -> bit-identical
     per-cell records.  Cells whose last wave holds only a few poses let that wave run far ahead of the team
