@@ -32,19 +32,7 @@
 namespace ipc {
 
 // ---- layout -----------------------------------------------------------------------------------------------------
-struct BandLayout {
-    int nb;          // band unknowns: columns 0 .. nb-1
-    int m;           // dense rows: the wide loops' unknowns (m - 1) and the right-hand side (last)
-    int W;           // stored band rows per column (row i of column j at offset i - j < W), >= 64
-    int ldb;         // column stride = W + m
-    int n;           // unknowns = nb + m - 1; rows 0 .. n
-    __host__ __device__ __forceinline__ size_t at(int i, int j) const { return (size_t)j * ldb + (i < nb ? i - j : W + (i - nb)); }
-    // is entry (i, j), i >= j, inside the stored profile?
-    __host__ __device__ __forceinline__ bool in(int i, int j) const { return i >= nb || i - j < W; }
-    // the same address in 32 bits (a system holds < 2^31 doubles): one v_mad_u32 instead of a 64-bit multiply
-    __device__ __forceinline__ unsigned at32(int i, int j) const { return (unsigned)j * (unsigned)ldb + (unsigned)(i < nb ? i - j : W + (i - nb)); }
-    __host__ __device__ size_t doubles() const { return (size_t)(n > 0 ? n : 1) * ldb + 64; }
-};
+// (struct BandLayout: cluster_common.hpp -- the literal normal equations of the Levenberg retry use the same layout)
 // the rows below a block column that ends in front of column k1 and can hold a non-zero of it: band rows k1 .. and every
 // dense row from max(k1, nb) on, numbered 0 .. R-1 ("virtual rows", the last one is the right-hand side)
 struct BandRows {

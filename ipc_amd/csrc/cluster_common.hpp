@@ -143,6 +143,97 @@ struct LoopTables {
     const int* ev_item(const int* d) const { return ev_ptr(d) + (L + 3); }
 };
 
+// ---- banded storage of an SPD system with a dense border (cluster_band.hpp has the factorisation) -----------------
+struct BandLayout {
+    int nb;          // band unknowns: columns 0 .. nb-1
+    int m;           // dense rows: the wide loops' unknowns (m - 1) and the right-hand side (last)
+    int W;           // stored band rows per column (row i of column j at offset i - j < W), >= 64
+    int ldb;         // column stride = W + m
+    int n;           // unknowns = nb + m - 1; rows 0 .. n
+    __host__ __device__ __forceinline__ size_t at(int i, int j) const { return (size_t)j * ldb + (i < nb ? i - j : W + (i - nb)); }
+    // is entry (i, j), i >= j, inside the stored profile?
+    __host__ __device__ __forceinline__ bool in(int i, int j) const { return i >= nb || i - j < W; }
+    // the same address in 32 bits (a system holds < 2^31 doubles): one v_mad_u32 instead of a 64-bit multiply
+    __device__ __forceinline__ unsigned at32(int i, int j) const { return (unsigned)j * (unsigned)ldb + (unsigned)(i < nb ? i - j : W + (i - nb)); }
+    __host__ __device__ size_t doubles() const { return (size_t)(n > 0 ? n : 1) * ldb + 64; }
+};
+
+struct PersistCtl;
+// factorisation + back substitution of one banded + bordered system on `workgroups` workgroups (cluster_band.hpp,
+// bband_test_kernel); *info: 0, or 1 + the first column of the block column whose pivot was not positive.  A / Lf:
+// B.doubles() each, dinv / x: B.n + 64 doubles, zero: a device word that holds 0.0
+inline hipError_t band_system_solve(const BandLayout& B, double* A, double* Lf, double* dinv, double* x, PersistCtl* ctl, int* info,
+                                    const double* zero, int workgroups, hipStream_t st);
+
+// ---- where the literal normal equations of the Levenberg retry are stored ------------------------------------------
+// g2o's own H (block tridiagonal from the chain + one off-diagonal block per loop with two free ends) is what carries the
+// damping (cluster_dogleg below).  Dense (rounds 3 - 5): (n + 1) x n column major, right-hand side in row n -- d L <= 24 000
+// unknowns.  Banded (round 6): the poses in chain order are a band of half-width (longest ordinary loop span + 1) blocks;
+// the later end of every loop that spans more goes to the dense border.  n (W + m) doubles instead of n^2: C5's clusters
+// (34 000 poses = 204 000 unknowns, spans <= 200) are 2 GB instead of 333 GB, and C4's (15 000 unknowns) factor in
+// n W^2 = 1.4e9 operations instead of n^3 / 3 = 1.1e12.
+struct DenseStore {
+    double* A; int nn, d;                                   // nn unknowns
+    __device__ __forceinline__ int unk(int p) const { return d * (p - 1); }
+    __device__ __forceinline__ int n() const { return nn; }
+    __device__ __forceinline__ double* lower(int i, int j) const { return &A[(size_t)j * (nn + 1) + i]; }     // i >= j; i == n: rhs
+};
+struct BandStore {
+    double* A; BandLayout B; const int* ublk; int d;        // ublk[p]: block of pose p in the band order (border poses last)
+    __device__ __forceinline__ int unk(int p) const { return d * ublk[p]; }
+    __device__ __forceinline__ int n() const { return B.n; }
+    __device__ __forceinline__ double* lower(int i, int j) const { return &A[B.at(i, j)]; }
+};
+// x in the store's unknown order -> [d (p - 1) + k], the order gk*_h_from_dense reads
+__global__ void gk_unpermute_blocks(const double* x, const int* ublk, int d, int L, double* out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < 1 || p > L) return;
+    for (int k = 0; k < d; ++k) out[(size_t)d * (p - 1) + k] = x[(size_t)d * ublk[p] + k];
+}
+
+// The band structure of the pose-space system: lf / lt = local end poses of the loops (0 = the gauge, fixed: no block).
+// S = the largest span that stays in the band; loops that span more send their later end to the border.  Chosen to make
+// L (S + 1 + border poses)^2 small; use == false: not worth it (the dense store is as good or the border would be huge).
+struct PoseBandPlan {
+    bool use = false;
+    int S = 0, nbp = 0, nborder = 0;
+    std::vector<int> ublk;                                  // [L + 1]
+};
+inline PoseBandPlan pose_band_plan(int d, int L, int nl, const int* lf, const int* lt, int max_border = 64)
+{
+    PoseBandPlan P;
+    std::vector<int> span;
+    span.reserve(nl);
+    for (int l = 0; l < nl; ++l)
+        if (lf[l] >= 1 && lt[l] >= 1 && lf[l] != lt[l]) span.push_back(std::abs(lt[l] - lf[l]));
+    std::vector<int> s(span);
+    std::sort(s.begin(), s.end());
+    // candidates: keep every loop (S = largest span), or cut behind the k widest
+    double best = -1.0;
+    int bestS = 1;
+    const int ns = (int)s.size();
+    for (int k = 0; k <= std::min(ns, max_border); ++k) {
+        const int S = std::max(1, k < ns ? s[ns - 1 - k] : 1);
+        const double w = (double)(S + 1) + k;                // (at most k border poses)
+        const double cost = (double)L * w * w;
+        if (best < 0 || cost < best) { best = cost; bestS = S; }
+    }
+    P.S = bestS;
+    std::vector<char> border(L + 1, 0);
+    for (int l = 0; l < nl; ++l)
+        if (lf[l] >= 1 && lt[l] >= 1 && std::abs(lt[l] - lf[l]) > P.S) border[std::max(lf[l], lt[l])] = 1;
+    P.ublk.assign(L + 1, 0);
+    int nb = 0;
+    for (int p = 1; p <= L; ++p) if (!border[p]) P.ublk[p] = nb++;
+    P.nbp = nb;
+    for (int p = 1; p <= L; ++p) if (border[p]) P.ublk[p] = nb++;
+    P.nborder = L - P.nbp;
+    const double wd = (double)d * (P.S + 1) + (double)d * P.nborder;
+    P.use = P.nbp >= 1 && wd * 3.0 <= (double)d * L;         // (a third of the dense width at most: otherwise the dense store)
+    return P;
+}
+
 // Ops:  evaluate_committed(chi) | linearize(bb, bHb, hh, bh, info) | blend(alpha, c, bma)
 //       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
 //       | damped_solve(lambda, ok, hh, bh, bHh, hHh)   (H + lambda I) h = b on the literal normal equations

@@ -462,18 +462,23 @@ __device__ __forceinline__ void gk_atob(const double (&A)[3][3], const Sym3& om,
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[r][c] += A[0][r] * OB[0][c] + A[1][r] * OB[1][c] + A[2][r] * OB[2][c];
 }
-__global__ void gk_dense_H(ClusterDev D, double* Hd, double lambda)
+// St: DenseStore or BandStore (cluster_common.hpp) -- where entry (i, j), i >= j, of the lower triangle lives
+template <class St>
+__global__ void gk_literal_H(ClusterDev D, St S, double lambda)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < 1 || p > D.L) return;
-    const int n = 3 * D.L, ldh = n + 1;
     double dg[3][3] = {{lambda, 0, 0}, {0, lambda, 0}, {0, 0, lambda}};
     auto put = [&](int prow, int pcol, const double (&B)[3][3], bool add) {      // block (prow, pcol), prow > pcol >= 1
+        const int ui0 = S.unk(prow), uj0 = S.unk(pcol);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                double* q = &Hd[(size_t)(3 * (pcol - 1) + c) * ldh + 3 * (prow - 1) + r];
+                // (a banded store orders the border poses last: the block may sit above the diagonal there, and the lower
+                // triangle holds its transpose)
+                const int ui = ui0 + r, uj = uj0 + c;
+                double* q = ui >= uj ? S.lower(ui, uj) : S.lower(uj, ui);
                 *q = add ? *q + B[r][c] : B[r][c];
             }
     };
@@ -505,11 +510,12 @@ __global__ void gk_dense_H(ClusterDev D, double* Hd, double lambda)
             put(p, other, off, true);                  // (several loops may join the same pair: accumulated in list order)
         }
     }
+    const int u0 = S.unk(p);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c <= r; ++c) Hd[(size_t)(3 * (p - 1) + c) * ldh + 3 * (p - 1) + r] = dg[r][c];
-        Hd[(size_t)(3 * (p - 1) + r) * ldh + n] = D.b[r * D.ld + p];
+        for (int c = 0; c <= r; ++c) *S.lower(u0 + r, u0 + c) = dg[r][c];
+        *S.lower(S.n(), u0 + r) = D.b[r * D.ld + p];
     }
 }
 // h <- the dense solution; partial |h|^2, b.h
@@ -700,7 +706,7 @@ inline hipError_t ClusterSolver2::damped_solve(double lambda, bool& ok, double& 
     }
     IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
-    hipLaunchKernelGGL(gk_dense_H, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, d_H_, lambda);
+    hipLaunchKernelGGL(gk_literal_H<DenseStore>, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, DenseStore{d_H_, n, 3}, lambda);
     IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));      // (solution in the scan workspace: 3 ld doubles)
     hipLaunchKernelGGL(gk_h_from_dense, dim3(nblk_), dim3(kGB), 0, st_, D, (const double*)D.sc);
     sum_partials(2, 2);

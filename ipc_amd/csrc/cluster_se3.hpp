@@ -611,22 +611,24 @@ __device__ __forceinline__ void gk3_atob(const double (&A)[6][6], const double* 
         }
     }
 }
-__global__ void gk3_dense_H(ClusterDev3 D, double* Hd, double lambda)
+template <class St>
+__global__ void gk3_literal_H(ClusterDev3 D, St S, double lambda)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < 1 || p > D.L) return;
-    const int n = 6 * D.L, ldh = n + 1;
     double dg[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) dg[r][c] = r == c ? lambda : 0.0;
     auto put = [&](int prow, int pcol, const double (&B)[6][6], bool add) {
+        const int ui0 = S.unk(prow), uj0 = S.unk(pcol);
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                double* q = &Hd[(size_t)(6 * (pcol - 1) + c) * ldh + 6 * (prow - 1) + r];
+                const int ui = ui0 + r, uj = uj0 + c;         // (cluster_se2.hpp::gk_literal_H)
+                double* q = ui >= uj ? S.lower(ui, uj) : S.lower(uj, ui);
                 *q = add ? *q + B[r][c] : B[r][c];
             }
     };
@@ -673,11 +675,12 @@ __global__ void gk3_dense_H(ClusterDev3 D, double* Hd, double lambda)
             put(p, other, off, true);
         }
     }
+    const int u0 = S.unk(p);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
 #pragma unroll
-        for (int c = 0; c <= r; ++c) Hd[(size_t)(6 * (p - 1) + c) * ldh + 6 * (p - 1) + r] = dg[r][c];
-        Hd[(size_t)(6 * (p - 1) + r) * ldh + n] = D.b[(size_t)r * D.ld + p];
+        for (int c = 0; c <= r; ++c) *S.lower(u0 + r, u0 + c) = dg[r][c];
+        *S.lower(S.n(), u0 + r) = D.b[(size_t)r * D.ld + p];
     }
 }
 __global__ void gk3_h_from_dense(ClusterDev3 D, const double* x)
@@ -865,7 +868,7 @@ inline hipError_t ClusterSolver3::damped_solve(double lambda, bool& ok, double& 
     }
     IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
-    hipLaunchKernelGGL(gk3_dense_H, dim3((D.L + 1 + 63) / 64), dim3(64), 0, st_, D, d_H_, lambda);
+    hipLaunchKernelGGL(gk3_literal_H<DenseStore>, dim3((D.L + 1 + 63) / 64), dim3(64), 0, st_, D, DenseStore{d_H_, n, 6}, lambda);
     IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));      // (solution in the scan workspace: 6 ld doubles)
     hipLaunchKernelGGL(gk3_h_from_dense, dim3(nblk_), dim3(kGB), 0, st_, D, (const double*)D.sc);
     sum_partials(2, 2);

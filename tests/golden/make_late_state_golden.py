@@ -86,6 +86,59 @@ def work(args):
     return out
 
 
+def forward(args):
+    """From dumped state i the oracle runs ON ITS OWN through the candidates that follow (its state evolves by its own
+    accepts) up to position `stop`: one record per candidate, appended to late_forward_<tag>.jsonl.  Stops early when its
+    decision differs from the GPU run's (from there on the two states differ and nothing compares)."""
+    tag, i, stop = args
+    from oracle import oracle as O
+    import bench
+    d = np.load(dump_path(tag))
+    g, cfg, _ = bench.build_workload(WORKLOAD[tag])
+    O.set_wide_dots(True)
+    inc = O.IncrementalIPC(g.dim, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                           cfg.slow_reject_th, cfg.slow_reject_iter_base, g.loop_ids, g.loop_meas, g.loop_info)
+    order = d["order"]
+    if i < 0:
+        # from the END of the oracle's own prefix run (c4_ / c5_incremental_expected.npz): its poses up to the last vertex a
+        # checked candidate touches, odometry beyond (nothing behind the last accept's window was ever optimised)
+        exp = np.load(os.path.join(HERE, "%s_incremental_expected.npz" % tag))
+        poses = inc.poses()
+        m = exp["poses"].shape[0]
+        poses[:m] = exp["poses"]
+        for v in range(m, poses.shape[0]):
+            poses[v] = O.pose_mul(g.dim, poses[v - 1], O.meas_to_pose(g.dim, g.odom_meas[v - 1]))
+        inc.set_state(poses, exp["consensus"])
+        q0 = len(exp["order"])
+    else:
+        q0 = int(d["positions"][i])
+        rec = d["records"][q0]
+        lo, hi = int(rec["lo"]), int(rec["hi"])
+        poses = inc.poses()
+        # (the window of THIS candidate's cluster; the candidates that follow reach at most a little further, into poses
+        # that are pure odometry on top of the window's last pose -- as in the run itself, see below)
+        poses[lo:hi + 1] = window_to_poses(g.dim, d["window"][d["window_off"][i]:d["window_off"][i + 1]])
+        for v in range(hi + 1, poses.shape[0]):
+            poses[v] = O.pose_mul(g.dim, poses[v - 1], O.meas_to_pose(g.dim, g.odom_meas[v - 1]))
+        inc.set_state(poses, d["cns"][d["cns_off"][i]:d["cns_off"][i + 1]])
+    path = os.path.join(ROOT, "gpurun_out", "late_forward_%s.jsonl" % tag)
+    n, t0 = 0, time.perf_counter()
+    for q in range(q0, stop):
+        k = int(order[q])
+        t1 = time.perf_counter()
+        ok, info = inc.agreement_check(k)
+        r = d["records"][q]
+        out = dict(start=int(i), q=q, k=k, decision=bool(ok), lo=info["lo"], hi=info["hi"], cluster=info["cluster"],
+                   iterations=info["iterations"], max_chi2=info["max_chi2"], seconds=round(time.perf_counter() - t1, 2),
+                   gpu_decision=bool(r["ok"]), gpu_max_chi2=float(r["max_chi2"]))
+        with open(path, "a") as f:
+            f.write(json.dumps(out) + "\n")
+        n += 1
+        if bool(ok) != bool(r["ok"]):
+            break
+    return dict(tag=tag, start=int(i), first=q0, done=n, stop=stop, seconds=round(time.perf_counter() - t0, 1))
+
+
 def assemble(tag):
     d = np.load(dump_path(tag))
     res = {}
@@ -133,9 +186,32 @@ def main():
     ap.add_argument("--max-iterations-gpu", type=int, default=10 ** 9,
                     help="skip positions whose GPU solve took more dog-leg iterations than this (oracle time)")
     ap.add_argument("--assemble", action="store_true")
+    ap.add_argument("--forward", type=int, default=0,
+                    help="from every dumped state (and from the end of the oracle's own prefix run) the oracle runs on by itself "
+                         "through at most this many candidates, or up to the next dumped state")
     a = ap.parse_args()
     if a.assemble:
         return assemble(a.tag)
+    if a.forward > 0:
+        d = np.load(dump_path(a.tag))
+        pos = [int(q) for q in d["positions"]]
+        n = len(d["order"])
+        jobs = []
+        exp = os.path.join(HERE, "%s_incremental_expected.npz" % a.tag)
+        if os.path.exists(exp):
+            q0 = len(np.load(exp)["order"])
+            if q0 < pos[0]:
+                jobs.append((a.tag, -1, min(pos[0], q0 + a.forward)))
+        for i, q in enumerate(pos):
+            nxt = pos[i + 1] if i + 1 < len(pos) else n
+            jobs.append((a.tag, i, min(nxt, q + a.forward)))
+        jobs.sort(key=lambda j: -(j[2] - (pos[j[1]] if j[1] >= 0 else 0)))
+        print("%s: %d forward stretches on %d workers" % (a.tag, len(jobs), a.workers), flush=True)
+        from multiprocessing import Pool
+        with Pool(a.workers) as pool:
+            for out in pool.imap_unordered(forward, jobs):
+                print(json.dumps(out), flush=True)
+        return
     d = np.load(dump_path(a.tag))
     todo = list(range(len(d["positions"])))
     if a.only:
