@@ -342,7 +342,7 @@ def executed_flops(workload, dim):
     counts: x 64 lanes, FMA = 2 flops).  `current` says whether the pass was taken on the kernel sources of this build
     (sidecar .meta.json written by tools/r4_profile.sh sq; passes without one predate the check).  None: no such file."""
     import csv
-    for rnd in ("r5", "r4", "r3", "r2"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.csv" % (rnd, workload.lower()))
         if os.path.exists(path):
             break
@@ -439,7 +439,7 @@ def main():
     # (FETCH_SIZE / WRITE_SIZE in KB, separate passes; FETCH_SIZE doubled per the gfx950 note in
     # MI355X_MICROARCH.md).  Per step, like `achieved`.
     traffic = None
-    for rnd in ("r5_", "r4_", ""):
+    for rnd in ("r6_", "r5_", "r4_", ""):
         pmc_csv = os.path.join(ROOT, "profiles", "%spmc_hbm_%s.csv" % (rnd, args.workload))
         if os.path.exists(pmc_csv):
             break
@@ -514,6 +514,27 @@ def main():
     }
     bits, acc = sm.result()
     out["accepted"] = int(acc.sum())
+    if ms_per_step < 5000.0:
+        # A SINGLE-SHOT matrix: a second engine of the same graph (kernels loaded, streams there), its FIRST step -- the two
+        # planning passes with their host read-back, the buffers' hipMalloc, cells solved in list order (the repeated steps
+        # above run on the cached cell lists, slow cells first, include/ipc_amd.h "stream contract").  All ranks take part.
+        eng1 = IPC(g, cfg, device=local_rank)
+        sm1 = ShardedMatrix(EngineBackend(eng1), rank, world)
+        barrier()
+        t0f = time.perf_counter()
+        sm1.step()
+        barrier()
+        first_ms = (time.perf_counter() - t0f) * 1e3
+        if world > 1:
+            t = torch.tensor([first_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            first_ms = float(t.item())
+        _, acc1 = sm1.result()
+        out["first_step_ms"] = first_ms
+        out["first_step_same_accepted_set"] = bool(np.array_equal(acc1, acc))
+        out["first_step_note"] = ("single-shot matrix on a fresh engine: planning passes + host read-back + buffer allocation + cells in list "
+                                  "order; ms_per_step is a repeated step on the cached cell lists (slow cells first)")
+        eng1.close()
     out["solved_cells_rank0"] = int(len(cells))
     # cells whose intervals do not overlap cost nothing (C[i][j] = C[i][i] & C[j][j]): `value` counts them, as the metric
     # is defined over all N(N+1)/2 pairs; the rate over the cells that are actually solved is the one to compare with

@@ -144,9 +144,9 @@ typedef struct {
     int cells;               /* solved cells                                                   */
     int long_cells;          /* of those, solved by the cluster-solver fallback                */
     int failed_cells;        /* the optimisation ended in g2o's Fail state (flags & 2): the linear solve kept meeting
-                                non-positive pivots up to the largest Levenberg damping (or the sub-problem is too
-                                large for the damped solver, > 24 000 unknowns); the cell's chi2 is that of the last
-                                good state                                                                          */
+                                non-positive pivots up to the largest Levenberg damping (or the sub-problem has more than
+                                24 000 unknowns AND no band structure, ipc_incremental_counters); the cell's chi2 is that
+                                of the last good state                                                              */
     int capped_cells;        /* ran to the iteration cap without the dog-leg terminating       */
     int nan_cells;           /* max chi2 is NaN (counts as "agrees", like chi2 > th does in
                                 the reference, src/consensus_utils.cpp:18)                     */
@@ -241,6 +241,23 @@ int ipc_incremental_prepare(ipc_engine_t* h);
  * served correctly as well: the candidate asked for moves to the head of the engine's prediction and the solves behind
  * it stay valid (they assumed rejects in front of them); an edit of the set throws the work done ahead away. */
 int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_check_info_t* info);
+
+/* What the faithful mode had to do besides the plain device-resident solve since the engine was created (diagnostics; the
+ * decisions are the same either way):
+ *   lost_launches          persistent launches whose grid barrier gave up (a workgroup never became resident: foreign work on
+ *                          the GPU).  In the look-ahead pipeline the check is redone alone when its turn comes; a check that runs
+ *                          alone is launched again, twice (relaunches), before the host-driven kernels take over
+ *   host_solver_fallbacks  checks redone by the host-driven solver: lost three times, or the capacitance factorisation met a
+ *                          non-positive pivot -- g2o's Levenberg retry (src/utils.cpp:104-105, "dl_var") on the literal normal
+ *                          equations follows
+ *   literal_band_solves    damped solves that factored the literal normal equations in the banded + bordered layout (round 6:
+ *                          any cluster size; dense store below IPC_LITERAL_BAND_MIN_N = 3 072 unknowns or without a band,
+ *                          and then only up to 24 000 unknowns -- beyond that the optimisation ends in Fail and the candidate
+ *                          is rejected) */
+typedef struct {
+    long host_solver_fallbacks, lost_launches, relaunches, literal_band_solves;
+} ipc_incremental_counters_t;
+int ipc_incremental_counters(ipc_engine_t* h, ipc_incremental_counters_t* out);
 
 /* IPC::getMaxConsensusSet (include/ipc/consensus.hpp:16): candidate FILE indices in set order. */
 int ipc_consensus_size(ipc_engine_t* h, int* n);

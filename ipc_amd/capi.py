@@ -30,7 +30,7 @@ SYMBOLS = [
     "ipc_run", "ipc_cell_count", "ipc_cell_info", "ipc_solve_report", "ipc_solver_time_ms", "ipc_synchronize",
     "ipc_incremental_reset", "ipc_incremental_prepare", "ipc_agreement_check", "ipc_consensus_size", "ipc_consensus_set",
     "ipc_remove_from_consensus", "ipc_add_to_consensus", "ipc_current_poses", "ipc_final_optimize",
-    "ipc_debug_dense_solve", "ipc_debug_band_solve", "ipc_debug_band_plan", "ipc_debug_absorbed_edges", "ipc_append_candidate", "ipc_incremental_set_state", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
+    "ipc_debug_dense_solve", "ipc_debug_band_solve", "ipc_debug_band_plan", "ipc_debug_absorbed_edges", "ipc_append_candidate", "ipc_incremental_set_state", "ipc_incremental_counters", "ipc_row_assignment", "ipc_run_sharded", "ipc_run_set_only",
 ]
 
 
@@ -50,6 +50,11 @@ class CheckInfo(C.Structure):
     _fields_ = [("lo", C.c_int), ("hi", C.c_int), ("n_cluster_loops", C.c_int), ("iterations", C.c_int),
                 ("tries", C.c_int), ("flags", C.c_int), ("max_chi2", C.c_double), ("chi2_total", C.c_double),
                 ("chi2_initial", C.c_double)]
+
+
+class IncrementalCounters(C.Structure):
+    _fields_ = [("host_solver_fallbacks", C.c_long), ("lost_launches", C.c_long), ("relaunches", C.c_long),
+                ("literal_band_solves", C.c_long)]
 
 
 class SolveReport(C.Structure):
@@ -114,6 +119,7 @@ def load():
     lib.ipc_add_to_consensus.argtypes = [vp, ip]
     lib.ipc_current_poses.argtypes = [vp, vp]
     lib.ipc_incremental_set_state.argtypes = [vp, vp, vp, ip, ip]
+    lib.ipc_incremental_counters.argtypes = [vp, C.POINTER(IncrementalCounters)]
     lib.ipc_final_optimize.argtypes = [vp, vp, ip, vp, C.POINTER(CheckInfo)]
     lib.ipc_debug_dense_solve.argtypes = [ip, vp, ip, ip, vp, C.POINTER(ip)]
     lib.ipc_debug_band_solve.argtypes = [ip, ip, ip, vp, ip, vp, C.POINTER(ip)]

@@ -161,6 +161,12 @@ class IPC:
         capi.check(self.lib.ipc_incremental_set_state(self.h, _p(poses), _p(cns), int(cns.shape[0]), int(resume_position)))
         self._max_consensus_set = cns.copy()
 
+    def incremental_counters(self):
+        """dict(host_solver_fallbacks, lost_launches, relaunches, literal_band_solves) -- ipc_incremental_counters."""
+        c = capi.IncrementalCounters()
+        capi.check(self.lib.ipc_incremental_counters(self.h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in capi.IncrementalCounters._fields_}
+
     def final_optimize(self, accepted, iterations=1000):
         """The harness's final map (reference src/simulation.cpp:50-65): returns (poses [V,3] or
         [V,12] (R row-major, t), CheckInfo with chi2_total)."""

@@ -234,6 +234,11 @@ inline PoseBandPlan pose_band_plan(int d, int L, int nl, const int* lf, const in
     return P;
 }
 
+struct LiteralBand;                                         // cluster_literal_band.hpp
+inline void literal_band_free(LiteralBand* p);
+template <class Solver>
+hipError_t literal_band_damped(Solver& S, double lambda, bool& used, double* x_out, int* d_info);
+
 // Ops:  evaluate_committed(chi) | linearize(bb, bHb, hh, bh, info) | blend(alpha, c, bma)
 //       | trial(p, q, newChi, anyChanged) | commit() | max_edge_chi2(mx)
 //       | damped_solve(lambda, ok, hh, bh, bHh, hHh)   (H + lambda I) h = b on the literal normal equations
@@ -257,6 +262,7 @@ hipError_t cluster_dogleg(Ops& ops, int iterations, ClusterOut& out, double term
     for (int it = 0; it < iterations; ++it) {
         double bb, bHb, hh, bh;
         int info = 0;
+        ops.want_plain_solve(wasPD);                  // (once a factorisation has failed every step is a damped one: the capacitance system is not even set up)
         IPC_CL_CHK(ops.linearize(bb, bHb, hh, bh, info));
         double hHh = bh, bHh = bb;                    // H h_gn = b (plain solve)
         {

@@ -596,8 +596,22 @@ public:
     void commit() { std::swap(dev_.X, dev_.Xn); std::swap(dev_.e, dev_.en); std::swap(dev_.le, dev_.len); }
     hipError_t max_edge_chi2(double& mx);
     hipError_t damped_solve(double lambda, bool& ok, double& hh, double& bh, double& bHh, double& hHh);
-    bool allow_damping = true;          // Levenberg retry of a failed linear solve (dense normal equations, <= kMaxDenseN unknowns)
+    bool allow_damping = true;          // Levenberg retry of a failed linear solve on the literal normal equations: banded + bordered store
+                                        // (cluster_literal_band.hpp) where the loops form a band, dense up to kMaxDenseN unknowns otherwise
     static constexpr int kMaxDenseN = 24000;
+    static constexpr int kD = 3;
+    int literal_band_min_n = 3072;      // IPC_LITERAL_BAND_MIN_N: smaller systems keep the dense store (bit for bit as in rounds 3 - 5); < 0: never banded
+    LiteralBand* lband = nullptr; bool lband_stale = true;
+    void want_plain_solve(bool w) { want_plain_ = w; }
+    bool want_plain_ = true;
+    long literal_band_solves() const;
+    const LoopTables& tables() const { return tab_; }
+    hipStream_t stream() const { return st_; }
+    template <class St> void launch_literal_H(const St& S, double lambda)
+    {
+        auto& D = dev_;
+        hipLaunchKernelGGL(gk_literal_H<St>, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, S, lambda);
+    }
 
 private:
     double* d_H_ = nullptr; size_t capH_ = 0;       // dense system + factor of damped_solve
@@ -613,6 +627,7 @@ private:
 
     void release()
     {
+        if (lband) { literal_band_free(lband); lband = nullptr; }
         hipFree(d_edge_); hipFree(d_loop_); hipFree(d_S_); hipFree(d_partial_); hipFree(d_scal_);
         hipFree(d_int_); hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
         if (h_scal_) hipHostFree(h_scal_);
@@ -673,6 +688,12 @@ inline hipError_t ClusterSolver2::linearize(double& bb, double& bHb, double& hh,
     sum_partials(1, 0);
     hipLaunchKernelGGL(gk_bHb_psi, grid, block, 0, st_, D);
     sum_partials(1, 1);
+    if (!want_plain_) {                              // cluster_dogleg: only b, b^T b and b^T H b are needed, a damped solve follows
+        IPC_CL_CHK(hipGetLastError());
+        IPC_CL_CHK(fetch(4));
+        bb = h_scal_[0]; bHb = h_scal_[1]; hh = 0.0; bh = 0.0; info = 1;
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(gk_scan, dim3(9), dim3(1024), 0, st_, D.ps, 9, L, ld);
     hipLaunchKernelGGL(gk_assemble, dim3((nl + 63) / 64, nl), dim3(64), 0, st_, D);
     IPC_CL_CHK(chol_solve_device(D.S, D.S + (size_t)(3 * nl + 1) * (3 * nl), 3 * nl, D.rhs, d_info_, st_));
@@ -697,17 +718,22 @@ inline hipError_t ClusterSolver2::damped_solve(double lambda, bool& ok, double& 
     ClusterDev& D = dev_;
     const int n = 3 * D.L;
     ok = false;
-    if (n > kMaxDenseN) return hipSuccess;                       // (too large for the dense fallback: the solve reports Fail)
-    const size_t m = (size_t)(n + 1) * n;
-    if (2 * m > capH_) {
-        hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
-        IPC_CL_CHK(hipMalloc(&d_H_, sizeof(double) * 2 * m));
-        capH_ = 2 * m;
-    }
-    IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
     IPC_CL_CHK(hipMemsetAsync(d_info_, 0, sizeof(int), st_));
-    hipLaunchKernelGGL(gk_literal_H<DenseStore>, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, DenseStore{d_H_, n, 3}, lambda);
-    IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));      // (solution in the scan workspace: 3 ld doubles)
+    bool banded = false;
+    if (literal_band_min_n >= 0 && n >= literal_band_min_n)
+        IPC_CL_CHK(literal_band_damped(*this, lambda, banded, D.sc, d_info_));   // (solution in the scan workspace: 3 ld doubles)
+    if (!banded) {
+        if (n > kMaxDenseN) return hipSuccess;                   // (no band and too large for the dense store: the solve reports Fail)
+        const size_t m = (size_t)(n + 1) * n;
+        if (2 * m > capH_) {
+            hipFree(d_H_); d_H_ = nullptr; capH_ = 0;
+            IPC_CL_CHK(hipMalloc(&d_H_, sizeof(double) * 2 * m));
+            capH_ = 2 * m;
+        }
+        IPC_CL_CHK(hipMemsetAsync(d_H_, 0, sizeof(double) * m, st_));
+        hipLaunchKernelGGL(gk_literal_H<DenseStore>, dim3((D.L + 1 + kGB - 1) / kGB), dim3(kGB), 0, st_, D, DenseStore{d_H_, n, 3}, lambda);
+        IPC_CL_CHK(chol_solve_device(d_H_, d_H_ + m, n, D.sc, d_info_, st_));
+    }
     hipLaunchKernelGGL(gk_h_from_dense, dim3(nblk_), dim3(kGB), 0, st_, D, (const double*)D.sc);
     sum_partials(2, 2);
     hipLaunchKernelGGL(gk_quad_bh, dim3(nblk_), dim3(kGB), 0, st_, D);
@@ -785,6 +811,7 @@ inline hipError_t ClusterSolver2::solve(hipStream_t st, const double* chain, int
         D.partial = d_partial_; D.scal = d_scal_;
     }
     tab_.build(lo, hi, members, from, to);
+    lband_stale = true;
     IPC_CL_CHK(hipMemcpyAsync(d_int_, tab_.host.data(), sizeof(int) * tab_.size(), hipMemcpyHostToDevice, st));
     IPC_CL_CHK(hipStreamSynchronize(st));           // the host table is pageable and reused
     D.lfrom = tab_.lfrom(d_int_); D.lto = tab_.lto(d_int_); D.lcand = tab_.lcand(d_int_);

@@ -636,12 +636,15 @@ struct ipc_engine {
     double borderline_band = -1.0;                     // < 0: 4 sqrt(term_eps)
     int last_literal_cells = 0;
     long lm_fallbacks = 0;
-    long persist_timeouts = 0;                         // persistent launches whose grid barrier gave up: redone by the host-driven solver
+    long persist_timeouts = 0;                         // persistent launches whose grid barrier gave up (lost launches)
+    long persist_relaunches = 0;                       // ... that were launched again (cluster_solve: twice before the host-driven solver)
     bool cns_dups = false;                             // some edge sits in the consensus set more than once (an accepted re-check, src/consensus.cpp:70)
     PersistSolver<PersistSe2>* persist2 = nullptr;
     PersistSolver<PersistSe3>* persist3 = nullptr;
     unsigned long long* d_prof = nullptr;              // IPC_PERSIST_PROF=1: phase clocks of the persistent kernel's leader, printed by ipc_destroy
     int max_helpers = -1;                              // IPC_PERSIST_HELPERS
+    PersistKnobs knobs;                                            // IPC_BAND_* / IPC_PERSIST_FAULT_EVERY as they stood at ipc_create: every solver instance of the engine gets them
+    int literal_band_min_n = 3072;                     // IPC_LITERAL_BAND_MIN_N, likewise
     // Speculative candidate pipeline of the faithful mode (IPC_SPEC_WINDOW solves in flight, default 10; 1 = off).
     // A rejected candidate leaves the state untouched (reference src/consensus.cpp:63-67), so the checks of the candidates
     // that FOLLOW in the processing order can start from the same state before its verdict is known; and the state an
@@ -744,16 +747,29 @@ struct ipc_engine {
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
-// One pipeline at a time per process: the workgroup budget of spec_pump counts this engine's solves only, and two
-// pipelines that fill the GPU between them could each end up with half-resident kernels waiting for the other's CUs.
-static ipc_engine* g_active_pipeline = nullptr;
-static std::mutex g_pipeline_mu;                       // (engines of different host threads: ipc_run_sharded, callers with one engine per thread)
-// Held for the WHOLE of every call that reads or edits an engine's pipeline state (slots, parked results, tentative
-// states, head): a check on engine A stops the pipeline of engine B (spec_reset of a FOREIGN engine), which B's owner
-// thread may be pumping at that moment -- round 4 only guarded the pointer.  Recursive: a check that falls back to the
-// host-driven solver quiesces its own pipeline from inside.  Two threads that each run a faithful loop therefore take
-// turns check by check (they would undo each other's look-ahead anyway: one pipeline per process).
-static std::recursive_mutex g_pipeline_run_mu;
+// One pipeline at a time per DEVICE (round 6; per process until round 5): the workgroup budget of spec_pump counts one
+// engine's solves, and two pipelines that fill one GPU between them could each end up with half-resident kernels waiting
+// for the other's CUs.  Engines on DIFFERENT devices have nothing to share -- their own streams, their own CUs -- and keep
+// their look-ahead side by side: the faithful mode is "replicas only" across GPUs, and one process with an
+// engine per device (the C++ testers, IPC_AMD_DEVICES) used to have every check of one replica reset the other's pipeline.
+struct DevicePipeline {
+    ipc_engine* active = nullptr;
+    // Held for the WHOLE of every call that reads or edits the pipeline state of an engine on this device (slots, parked
+    // results, tentative states, head): a check on engine A stops the pipeline of engine B ON THE SAME DEVICE (spec_reset of
+    // a FOREIGN engine), which B's owner thread may be pumping at that moment -- round 4 only guarded the pointer.  Recursive:
+    // a check that falls back to the host-driven solver quiesces its own pipeline from inside.  Two threads that each run a
+    // faithful loop on ONE device therefore take turns check by check (they would undo each other's look-ahead anyway).
+    std::recursive_mutex run_mu;
+};
+static std::mutex g_pipeline_mu;                       // guards the maps below (engines of different host threads)
+static std::map<int, DevicePipeline*> g_device_pipeline;      // never freed: a mutex other threads may hold must not die
+static DevicePipeline& device_pipeline(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pipeline_mu);
+    DevicePipeline*& p = g_device_pipeline[device];
+    if (!p) p = new DevicePipeline();
+    return *p;
+}
 // The pipeline's streams belong to the PROCESS, per device, not to an engine: only one pipeline runs at a time, and beyond
 // about two dozen streams the runtime runs them one after the other -- a second live engine with sixteen streams of its own
 // was enough to take C1 from 0.56 to 1.2 s (round 4: the full test suite in one process).  Created on demand, never destroyed.
@@ -866,6 +882,8 @@ extern "C" int ipc_create(int dim, int n_vertices, const double* odom_meas, cons
     }
     if (const char* mh = getenv("IPC_PERSIST_HELPERS")) { if (*mh) h->max_helpers = atoi(mh); }
     if (const char* lm = getenv("IPC_LM_RETRY")) { if (*lm) h->lm_retry = atoi(lm) != 0; }
+    h->knobs = PersistKnobs::from_env();
+    if (const char* e = getenv("IPC_LITERAL_BAND_MIN_N")) { if (*e) h->literal_band_min_n = atoi(e); }
     if (const char* bb = getenv("IPC_BORDERLINE_BAND")) {
         if (*bb) {
             char* end = nullptr;
@@ -1031,11 +1049,12 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
 {
     if (!h) return IPC_OK;
     hipSetDevice(h->device);
-    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);       // (no other thread's check may be resetting this engine's pipeline)
+    DevicePipeline& dp = device_pipeline(h->device);
+    std::lock_guard<std::recursive_mutex> run_lk(dp.run_mu);               // (no other thread's check may be resetting this engine's pipeline)
     spec_quiesce(h, true);
     {
         std::lock_guard<std::mutex> lk(g_pipeline_mu);
-        if (g_active_pipeline == h) g_active_pipeline = nullptr;
+        if (dp.active == h) dp.active = nullptr;
     }
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
@@ -1227,7 +1246,7 @@ extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const doubl
     if (h->d_slot) { h->retired.push_back(h->d_slot); h->d_slot = nullptr; }
     h->slot_world = 0;
     {
-        std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
+        std::lock_guard<std::recursive_mutex> run_lk(device_pipeline(h->device).run_mu);
         spec_insert_position(h, k);
     }
     if (index_out) *index_out = k;
@@ -1319,21 +1338,30 @@ static hipError_t cluster_solve(ipc_engine* h, const double* chain, double* src,
     if (!h->slots.empty() && h->spec_head >= 0) { if (int rc = spec_quiesce(h, true)) return hipErrorUnknown; }
     h->last_persist = !force_host && h->persist && PersistSolver<PersistSe2>::fits(hi - lo, (int)members.size());
     if (h->last_persist) {
-        if (h->dim == 3) {
-            IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
-                                           h->h_from.data(), h->h_to.data(), iters));
-            IPC_CL_CHK(h->persist3->wait(o));
-            if (h->persist3->timed_out()) { o.flags |= 2; ++h->persist_timeouts; }
-        } else {
-            IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
-                                           h->h_from.data(), h->h_to.data(), iters));
-            IPC_CL_CHK(h->persist2->wait(o));
-            if (h->persist2->timed_out()) { o.flags |= 2; ++h->persist_timeouts; }
+        // A LOST launch (a grid barrier timed out: some workgroup of the launch never became resident, e.g. beside a foreign
+        // tenant's kernels) says nothing about the problem: the same launch is tried again -- the pipeline is quiesced here, so it
+        // has the GPU to itself as far as this process goes -- twice, before the host-driven kernels (which need no
+        // co-residency, one launch per phase) take over.  Round 5 went straight to them.
+        bool lost = false;
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if (h->dim == 3) {
+                IPC_CL_CHK(h->persist3->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                               h->h_from.data(), h->h_to.data(), iters));
+                IPC_CL_CHK(h->persist3->wait(o));
+                lost = h->persist3->timed_out();
+            } else {
+                IPC_CL_CHK(h->persist2->launch(h->own_stream, chain, h->estride, h->d_cand, h->cstride, src, h->V, lo, hi, members,
+                                               h->h_from.data(), h->h_to.data(), iters));
+                IPC_CL_CHK(h->persist2->wait(o));
+                lost = h->persist2->timed_out();
+            }
+            if (!lost) break;
+            ++h->persist_timeouts;
+            if (attempt < 2) ++h->persist_relaunches;
         }
-        // (a barrier that timed out -- workgroups not resident beside foreign work -- takes the same way out: redone below)
+        if (lost) o.flags |= 2;
         // a non-positive pivot in the capacitance factorisation: g2o would retry with Levenberg damping -- the
-        // host-driven solver does (dense normal equations), from the same start
-        const bool lost = h->dim == 3 ? h->persist3->timed_out() : h->persist2->timed_out();
+        // host-driven solver does (literal normal equations, banded or dense), from the same start
         if (!lost && (!(o.flags & 2) || !h->lm_retry)) return hipSuccess;
         h->last_persist = false;
         ++h->lm_fallbacks;
@@ -2107,9 +2135,12 @@ static int ensure_incremental(ipc_engine* h, const char* who)
             HIPCHK(hipMalloc(&h->d_cur, sizeof(double) * 12 * (size_t)h->V));
             HIPCHK(copy_d2d_now(h, h->d_cur, h->d_open, sizeof(double) * 12 * (size_t)h->V));
         }
-        if (!h->cluster3) { h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; h->cluster3->allow_damping = h->lm_retry; }
+        if (!h->cluster3) {
+            h->cluster3 = new ClusterSolver3(); h->cluster3->term_eps = h->term_eps; h->cluster3->allow_damping = h->lm_retry;
+            h->cluster3->literal_band_min_n = h->literal_band_min_n;
+        }
         if (!h->persist3) {
-            h->persist3 = new PersistSolver<PersistSe3>(); h->persist3->term_eps = h->term_eps; h->persist3->d_prof = h->d_prof;
+            h->persist3 = new PersistSolver<PersistSe3>(h->knobs); h->persist3->term_eps = h->term_eps; h->persist3->d_prof = h->d_prof;
             if (h->max_helpers >= 0) h->persist3->max_helpers = h->max_helpers;
         }
         return IPC_OK;
@@ -2122,9 +2153,12 @@ static int ensure_incremental(ipc_engine* h, const char* who)
         HIPCHK(hipMemcpyAsync(h->d_cur, h->d_open, sizeof(double) * 5 * (size_t)h->V, hipMemcpyDeviceToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));
     }
-    if (!h->cluster) { h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; h->cluster->allow_damping = h->lm_retry; }
+    if (!h->cluster) {
+        h->cluster = new ClusterSolver2(); h->cluster->term_eps = h->term_eps; h->cluster->allow_damping = h->lm_retry;
+        h->cluster->literal_band_min_n = h->literal_band_min_n;
+    }
     if (!h->persist2) {
-        h->persist2 = new PersistSolver<PersistSe2>(); h->persist2->term_eps = h->term_eps; h->persist2->d_prof = h->d_prof;
+        h->persist2 = new PersistSolver<PersistSe2>(h->knobs); h->persist2->term_eps = h->term_eps; h->persist2->d_prof = h->d_prof;
         if (h->max_helpers >= 0) h->persist2->max_helpers = h->max_helpers;
     }
     return IPC_OK;
@@ -2362,11 +2396,11 @@ static int spec_ensure(ipc_engine* h)
         HIPCHK(pipeline_stream(h->device, q, &sl.st));
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (h->dim == 3) {
-            sl.s3 = new PersistSolver<PersistSe3>(); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
+            sl.s3 = new PersistSolver<PersistSe3>(h->knobs); sl.s3->term_eps = h->term_eps; sl.s3->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s3->d_abort_word = h->d_abort + q;
             HIPCHK(sl.s3->reserve(h->V - 1, std::max(256, std::min(h->N + 1, 16384)), 256));
         } else {
-            sl.s2 = new PersistSolver<PersistSe2>(); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
+            sl.s2 = new PersistSolver<PersistSe2>(h->knobs); sl.s2->term_eps = h->term_eps; sl.s2->d_prof = q == 0 ? h->d_prof : nullptr;
             sl.s2->d_abort_word = h->d_abort + q;
             HIPCHK(sl.s2->reserve(h->V - 1, std::max(256, std::min(h->N + 1, 16384)), 256));
         }
@@ -2692,7 +2726,8 @@ static int spec_pump(ipc_engine* h)
         ipc_engine::SpecResult& R = h->spec_res[p];
         R = ipc_engine::SpecResult{};
         R.valid = true; R.state = sl.state; R.lo = sl.lo; R.hi = sl.hi; R.nclu = sl.nclu; R.o = o;
-        R.retry_host = lost || ((o.flags & 2) && h->lm_retry);                // (decided when its turn comes, by the host-driven solver)
+        if (lost) ++h->persist_timeouts;
+        R.retry_host = lost || ((o.flags & 2) && h->lm_retry);                // (decided when its turn comes: launched again alone, cluster_solve)
         R.agree = !R.retry_host && !(o.max_chi2 > sl.th);                     // consensus_utils.cpp:17-21
         ++h->pred_conf[sl.expect + 1][R.agree ? 1 : 0];
         {
@@ -2835,18 +2870,13 @@ static int spec_reset(ipc_engine* h)
 
 static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_check_info_t* info)
 {
-    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
+    DevicePipeline& dp = device_pipeline(h->device);
+    std::lock_guard<std::recursive_mutex> run_lk(dp.run_mu);
     if (int rc = spec_ensure(h)) return rc;
-    {
-        std::lock_guard<std::mutex> lk(g_pipeline_mu);
-        if (g_active_pipeline && g_active_pipeline != h) {
-            HIPCHK(hipSetDevice(g_active_pipeline->device));
-            const int rc = spec_reset(g_active_pipeline);
-            HIPCHK(hipSetDevice(h->device));
-            if (rc) return rc;
-        }
-        g_active_pipeline = h;
+    if (dp.active && dp.active != h) {                  // (another engine on THIS device: its look-ahead is given up)
+        if (int rc = spec_reset(dp.active)) return rc;
     }
+    dp.active = h;
     SpecTimer tm(h->spec_t_total);
     if (h->spec_head < 0) {                            // first call (or after a reset): the pipeline starts from the poses as they are
         if (int rc = spec_reset(h)) return rc;
@@ -2934,7 +2964,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
 // the poses / the set are about to be read or edited from outside the pipeline: nothing in flight may outlive that
 static int spec_quiesce(ipc_engine* h, bool state_changes)
 {
-    std::lock_guard<std::recursive_mutex> run_lk(g_pipeline_run_mu);
+    std::lock_guard<std::recursive_mutex> run_lk(device_pipeline(h->device).run_mu);
     if (h->slots.empty()) return IPC_OK;
     if (state_changes) return spec_reset(h);
     if (h->commit_count) HIPCHK(hipEventSynchronize(h->ev_commit));
@@ -2968,6 +2998,16 @@ extern "C" int ipc_agreement_check(ipc_engine_t* h, int k, int* agrees, ipc_chec
     h->handed[k] = 1;
     *agrees = agree ? 1 : 0;
     fill_info(info, c.lo, c.hi, c.nclu, o);
+    return IPC_OK;
+}
+
+extern "C" int ipc_incremental_counters(ipc_engine_t* h, ipc_incremental_counters_t* out)
+{
+    if (!h || !out) return fail(IPC_ERR_ARG, "ipc_incremental_counters: NULL argument");
+    out->host_solver_fallbacks = h->lm_fallbacks;
+    out->lost_launches = h->persist_timeouts;
+    out->relaunches = h->persist_relaunches;
+    out->literal_band_solves = (h->cluster ? h->cluster->literal_band_solves() : 0) + (h->cluster3 ? h->cluster3->literal_band_solves() : 0);
     return IPC_OK;
 }
 

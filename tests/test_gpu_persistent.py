@@ -469,25 +469,34 @@ def test_c2_faithful_run_against_the_oracle_fixture():
 
 
 def test_faithful_run_rates_do_not_fall_back_to_the_unscheduled_pipeline():
-    """Floors, not targets (round 4 on one MI355X: C2 1 150 - 1 200 candidates/s, C1 0.55 - 0.62 s; before the pipeline was
-    scheduled by predicted verdicts: 800 - 850 /s and 0.81 s; one solve at a time: 105 /s and 1.9 s).  Best of three, each
-    workload in a process of its own: in THIS process the engines of the tests before hold a few dozen streams, and beyond
-    about two dozen the runtime runs them one after the other (profiles/r4_pipeline_window_sweep.txt (f))."""
+    """The pipeline scheduled by predicted verdicts against the SAME pipeline with the predictor off (IPC_SPEC_PREDICT=0: the
+    round-3 rule), same box, same minute, each run in a process of its own -- a ratio, not an absolute floor (rounds 4 - 5
+    asserted 700 / 420 candidates/s, which measures the host as much as the engine; round 4 on one MI355X: C2 1 150 - 1 200
+    against 800 - 850 candidates/s, C1 0.55 - 0.62 s against 0.81 s, i.e. 1.35 - 1.45x).  Best of three per run.  (In THIS
+    process the engines of the tests before hold a few dozen streams, and beyond about two dozen the runtime runs them one
+    after the other: profiles/r4_pipeline_window_sweep.txt (f).)"""
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    for k in ("IPC_SPEC_WINDOW", "IPC_CLUSTER_MODE", "GPU_MAX_HW_QUEUES"):
-        env.pop(k, None)
-    for workload, floor in (("C2", 700.0), ("C1", 420.0)):
+    base = dict(os.environ)
+    for k in ("IPC_SPEC_WINDOW", "IPC_CLUSTER_MODE", "GPU_MAX_HW_QUEUES", "IPC_SPEC_PREDICT"):
+        base.pop(k, None)
+
+    def rate(workload, **extra):
+        env = dict(base)
+        env.update(extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "lib_incremental.py"), os.path.join(root, "ipc_amd", "libipc_amd.so"),
                             workload, "3"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         m = re.search(r"([0-9.]+) candidates/s", r.stdout)
         assert m, r.stdout
-        print("\n[faithful run, %s] %s candidates/s" % (workload, m.group(1)))
-        assert float(m.group(1)) >= floor, r.stdout
+        return float(m.group(1))
+
+    for workload in ("C2", "C1"):
+        scheduled, plain = rate(workload), rate(workload, IPC_SPEC_PREDICT="0")
+        print("\n[faithful run, %s] %.0f candidates/s; with the predictor off %.0f (x %.2f)" % (workload, scheduled, plain, scheduled / plain))
+        assert scheduled >= 1.1 * plain, (workload, scheduled, plain)
 
 
 @pytest.mark.parametrize("workload,tag", [("C1", "c1"), ("C2", "c2")])
