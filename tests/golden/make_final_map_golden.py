@@ -23,7 +23,7 @@ import numpy as np
 
 from oracle import oracle as O
 
-WORKLOAD = {"c1": "C1", "c2": "C2", "c4": "C4"}
+WORKLOAD = {"c1": "C1", "c2": "C2", "c4": "C4", "c5": "C5"}
 
 
 def accepted_set(tag, g):

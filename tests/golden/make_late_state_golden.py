@@ -51,8 +51,11 @@ def window_to_poses(dim, w):
     return np.concatenate([R, w[:, 4:7]], axis=1)
 
 
+DUMP_SUFFIX = os.environ.get("IPC_LATE_DUMP_SUFFIX", "")       # (a second dump of the same run: evenly spaced re-synchronisation points)
+
+
 def dump_path(tag):
-    return os.path.join(ROOT, "gpurun_out", "late_states_%s.npz" % tag)
+    return os.path.join(ROOT, "gpurun_out", "late_states_%s%s.npz" % (tag, DUMP_SUFFIX))
 
 
 def work(args):
@@ -114,6 +117,8 @@ def forward(args):
         q0 = int(d["positions"][i])
         rec = d["records"][q0]
         lo, hi = int(rec["lo"]), int(rec["hi"])
+        if "window_lo" in d.files:                        # (evenly spaced re-synchronisation points dump a wider window)
+            lo, hi = int(d["window_lo"][i]), int(d["window_hi"][i])
         poses = inc.poses()
         # (the window of THIS candidate's cluster; the candidates that follow reach at most a little further, into poses
         # that are pure odometry on top of the window's last pose -- as in the run itself, see below)
@@ -154,6 +159,16 @@ def assemble(tag):
         cns.append(c); cns_off.append(cns_off[-1] + len(c))
         win.append(w); win_off.append(win_off[-1] + len(w))
     R = [res[i] for i in idx]
+    # the forward stretches (--forward): from each dumped state, and from the end of its own prefix run, the oracle went on BY
+    # ITSELF through the candidates that follow -- one record per position, the first one kept where stretches overlap
+    fwd = {}
+    fpath = os.path.join(ROOT, "gpurun_out", "late_forward_%s.jsonl" % tag)
+    if os.path.exists(fpath):
+        for line in open(fpath):
+            r = json.loads(line)
+            fwd.setdefault(r["q"], r)
+    fq = sorted(fwd)
+    F = [fwd[q] for q in fq]
     path = os.path.join(HERE, "%s_late_states.npz" % tag)
     np.savez_compressed(
         path, workload=WORKLOAD[tag], position=np.array([r["q"] for r in R], dtype=np.int32),
@@ -166,10 +181,20 @@ def assemble(tag):
         gpu_decision=np.array([r["gpu"]["decision"] for r in R], dtype=np.uint8),
         gpu_iterations=np.array([r["gpu"]["iterations"] for r in R], dtype=np.int32),
         gpu_max_chi2=np.array([r["gpu"]["max_chi2"] for r in R]), gpu_flags=np.array([r["gpu"]["flags"] for r in R], dtype=np.int32),
+        fwd_position=np.array(fq, dtype=np.int32), fwd_start=np.array([r["start"] for r in F], dtype=np.int32),
+        fwd_decision=np.array([r["decision"] for r in F], dtype=np.uint8), fwd_lo=np.array([r["lo"] for r in F], dtype=np.int32),
+        fwd_hi=np.array([r["hi"] for r in F], dtype=np.int32), fwd_cluster=np.array([r["cluster"] for r in F], dtype=np.int32),
+        fwd_iterations=np.array([r["iterations"] for r in F], dtype=np.int32), fwd_max_chi2=np.array([r["max_chi2"] for r in F]),
+        fwd_oracle_seconds=float(sum(r["seconds"] for r in F)),
         # the whole run the states were taken from (GPU): per-candidate records in processing order, for the full-run test
         run_decision=d["records"]["ok"], run_cluster=d["records"]["cluster"], run_lo=d["records"]["lo"], run_hi=d["records"]["hi"],
         run_max_chi2=d["records"]["max_chi2"], run_final_consensus=d["final_consensus"],
         loop_ids_checksum=d["loop_ids_checksum"], meas_checksum=d["meas_checksum"])
+    if F:
+        fw = max(abs(r["max_chi2"] - r["gpu_max_chi2"]) / max(abs(r["max_chi2"]), 1e-12) for r in F if r["max_chi2"] == r["max_chi2"])
+        print("%s forward stretches: %d positions (%d ... %d), decisions differing from the GPU run: %d, worst relative chi2 difference %.2e, "
+              "%.0f s of oracle time" % (tag, len(F), fq[0], fq[-1], sum(r["decision"] != r["gpu_decision"] for r in F), fw,
+                                         sum(r["seconds"] for r in F)))
     worst = max(abs(r["max_chi2"] - r["gpu"]["max_chi2"]) / max(abs(r["max_chi2"]), 1e-12) for r in R)
     print("%s: %d positions, decisions differing from the GPU run: %d, (lo, hi, cluster) differing: %d, worst relative chi2 "
           "difference %.2e, largest cluster %d loops, %.0f s of oracle time; %s (%d bytes)" %

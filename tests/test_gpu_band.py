@@ -242,20 +242,8 @@ def test_band_kernel_pipeline_and_helper_counts_change_no_bit(workload):
         assert np.array_equal(engs[0].current_poses().view(np.uint64), e.current_poses().view(np.uint64))
 
 
-def test_c4_prefix_against_the_oracle_fixture():
-    """BASELINE configs[3] as it is (sphere2500-like, ALL 2 450 true loops + 2 000 outliers): the candidates the CPU oracle
-    got through in its time budget -- clusters of hundreds of loops of span 50 plus the candidate, thousands of unknowns,
-    the banded solver by default."""
-    worst, big, eng = _replay("C4", "c4", 1e-6, {})
-    assert big >= 500
-    print("\n[C4 prefix] worst relative chi2 difference %.2e, largest cluster %d loops" % (worst, big))
-
-
-def test_c5_prefix_against_the_oracle_fixture():
-    """BASELINE configs[4] (V = 50 000, 5 000 true loops of span <= 200 + 20 000 local outliers), oracle prefix."""
-    worst, big, eng = _replay("C5", "c5", 1e-6, {})
-    assert big >= 300
-    print("\n[C5 prefix] worst relative chi2 difference %.2e, largest cluster %d loops" % (worst, big))
+# (round 6: the oracle's prefix runs of C4 / C5 are held against the WHOLE runs in tests/test_gpu_late_states.py::test_c{4,5}_full_faithful_run,
+# which execute those candidates anyway -- two separate replays of the prefixes were 17 s of a suite with a wall-clock limit)
 
 
 def test_c4_pipeline_is_bitwise_the_one_at_a_time_loop_through_the_band_kernel():
@@ -284,12 +272,12 @@ def test_r2k_full_run_against_the_oracle_fixture():
 
 def test_c5_pipeline_is_bitwise_the_one_at_a_time_loop():
     """The same on BASELINE configs[4] (V = 50 000: chain phases spread over every workgroup of a launch, 80 % expected
-    rejects on reduced workgroup counts, cluster search by the sweep once the set holds 512 edges): first 3 000 candidates."""
+    rejects on reduced workgroup counts): first 2 000 candidates."""
     import bench
     g, cfg, _ = bench.build_workload("C5")
     e1, ep = _engine(g, cfg, IPC_SPEC_WINDOW=1), _engine(g, cfg)
-    order = e1.candidate_order()[:3000]
-    r1, rp = _records(e1, order), _records(ep, order)
-    assert max(r[3] for r in r1) >= 500
+    order = e1.candidate_order()[:2000]                       # (3 000 until round 6: the whole run's late window is now held against
+    r1, rp = _records(e1, order), _records(ep, order)         #  the one-at-a-time loop as well, test_c5_full_faithful_run)
+    assert max(r[3] for r in r1) >= 250
     _assert_bitwise(r1, rp)
     assert np.array_equal(e1.current_poses().view(np.uint64), ep.current_poses().view(np.uint64))

@@ -131,6 +131,10 @@ def main():
     ap.add_argument("--limit", type=int, default=-1)
     ap.add_argument("--slow", type=int, default=3, help="rejects with the most iterations to include")
     ap.add_argument("--no-cap", action="store_true", help="no candidate at the iteration cap (hours of oracle time on C5)")
+    ap.add_argument("--even", type=int, default=0, help="instead of the picks above: this many positions evenly spaced from --even-from to the end "
+                                                        "(re-synchronisation points of the oracle's forward stretches, make_late_state_golden.py --forward)")
+    ap.add_argument("--even-from", type=int, default=0)
+    ap.add_argument("--suffix", default="", help="appended to the output file name")
     a = ap.parse_args()
     import bench
     from ipc_amd.consensus import IPC
@@ -141,7 +145,11 @@ def main():
         order = order[:a.limit]
     ids = np.asarray(g.loop_ids, dtype=np.int64).reshape(-1, 2)
     rec1, _, dt1, dig1 = run(eng, order, tag="pass 1")
-    chosen, why = pick(rec1, ids, order, cfg, a.positions, a.min_cluster, a.slow, not a.no_cap)
+    if a.even > 0:
+        chosen = sorted(set(int(q) for q in np.linspace(a.even_from, len(order) - 1, a.even + 1)[:-1]))
+        why = {q: "evenly spaced" for q in chosen}
+    else:
+        chosen, why = pick(rec1, ids, order, cfg, a.positions, a.min_cluster, a.slow, not a.no_cap)
     print("pass 1: %.1f s, accepted %d, largest cluster %d, digest %s; dumping %d positions" %
           (dt1, int(rec1["ok"].sum()), int(rec1["cluster"].max()), dig1, len(chosen)), flush=True)
     rec2, dumps, dt2, dig2 = run(eng, order, dump_at=set(chosen), tag="pass 2")
@@ -154,18 +162,27 @@ def main():
                reasons=np.array([why[q] for q in chosen]),
                loop_ids_checksum=np.int64(ids.sum()), meas_checksum=float(np.asarray(g.loop_meas).sum()))
     cns_all, cns_off, win_all, win_off = [], [0], [], [0]
+    wlo_all, whi_all = [], []
+    stride = (len(order) - a.even_from) // max(a.even, 1) + 1
     for q in chosen:
         poses, cns = dumps[q]
         lo, hi = int(rec1["lo"][q]), int(rec1["hi"][q])
+        if a.even > 0:
+            # a re-synchronisation point of a forward stretch: every pose a check of the stretch can read -- from the first
+            # vertex of any cluster the next candidates meet (pass 1 knows them) to the last vertex any accept has optimised
+            lo = int(rec1["lo"][q:q + stride + 1].min())
+            hi = int(max(rec1["hi"][:q + 1].max(), hi))
+        wlo_all.append(lo); whi_all.append(hi)
         w = poses[lo:hi + 1]
         if g.dim == 3:
             w = np.concatenate([rot_to_quat(w[:, :9]), w[:, 9:12]], axis=1)
         cns_all.append(cns.astype(np.int32)); cns_off.append(cns_off[-1] + len(cns))
         win_all.append(w); win_off.append(win_off[-1] + w.shape[0])
+    out.update(window_lo=np.array(wlo_all, dtype=np.int32), window_hi=np.array(whi_all, dtype=np.int32))
     out.update(cns=np.concatenate(cns_all) if cns_all else np.zeros(0, np.int32), cns_off=np.array(cns_off),
                window=np.concatenate(win_all) if win_all else np.zeros((0, 7)), window_off=np.array(win_off))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    path = os.path.join(ROOT, "gpurun_out", "late_states_%s.npz" % a.workload.lower())
+    path = os.path.join(ROOT, "gpurun_out", "late_states_%s%s.npz" % (a.workload.lower(), a.suffix))
     np.savez_compressed(path, **out)
     print(json.dumps(dict(workload=a.workload, candidates=len(order), seconds=[round(dt1, 2), round(dt2, 2)],
                           accepted=int(rec1["ok"].sum()), largest_cluster=int(rec1["cluster"].max()), digest=dig1,
@@ -184,9 +201,9 @@ def main():
         ok, info = e1.agreementCheck(k, with_info=True)
         exact = (ok, info.lo, info.hi, info.n_cluster_loops, info.iterations, info.tries) == (bool(r["ok"]), r["lo"], r["hi"], r["cluster"], r["iterations"], r["tries"]) \
             and np.float64(info.max_chi2).tobytes() == np.float64(r["max_chi2"]).tobytes()
-        lo, hi = int(r["lo"]), int(r["hi"])
-        inj = open_loop.copy()
         i = chosen.index(q)
+        lo, hi = wlo_all[i], whi_all[i]
+        inj = open_loop.copy()
         inj[lo:hi + 1] = window_to_poses(g.dim, win_all[i])
         e1.set_state(inj, cns, q)
         ok2, info2 = e1.agreementCheck(k, with_info=True)
