@@ -15,8 +15,10 @@ def export_recommended_environment():
     """The faithful incremental mode keeps up to 16 cluster solves in flight, one persistent launch per HIP stream; streams
     that share a hardware queue run one after the other and the runtime defaults to 4 queues.  GPU_MAX_HW_QUEUES is read
     once, when the HIP runtime initialises -- so it has to be in the environment before the first HIP call of the process
-    (torch's included).  That is the HOST PROGRAM's decision: bench.py, the tools and tests/conftest.py call this first
-    thing; importing the binding no longer edits the environment (round 5)."""
+    (torch's included).  That is the HOST PROGRAM's decision; importing the binding no longer edits the environment (round 5).
+    __graft_entry__.smoke() and tools/late_state_dump.py call this function; bench.py, tests/conftest.py and most tools set the
+    variable themselves (os.environ.setdefault at their top); a Python caller of ipc_amd.consensus.IPC that does neither runs
+    the faithful mode on 4 hardware queues -- the library says so once on stderr (spec_ensure)."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 

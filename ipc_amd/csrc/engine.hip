@@ -747,13 +747,16 @@ struct ipc_engine {
 };
 
 static int spec_quiesce(ipc_engine* h, bool state_changes);
-// One pipeline at a time per DEVICE (round 6; per process until round 5): the workgroup budget of spec_pump counts one
-// engine's solves, and two pipelines that fill one GPU between them could each end up with half-resident kernels waiting
-// for the other's CUs.  Engines on DIFFERENT devices have nothing to share -- their own streams, their own CUs -- and keep
-// their look-ahead side by side: the faithful mode is "replicas only" across GPUs, and one process with an
-// engine per device (the C++ testers, IPC_AMD_DEVICES) used to have every check of one replica reset the other's pipeline.
+static int spec_reset(ipc_engine* h);
+// The pipelines of one DEVICE share its CUs (round 6; until round 5 one pipeline per PROCESS: a check on engine B reset the
+// look-ahead of engine A).  Every workgroup of every persistent solve on a GPU must be resident, so the workgroup budget of
+// spec_pump counts the solves of EVERY engine on the device (foreign_busy below), each engine still runs its own window on
+// the device's one stream pool, and nobody resets anybody: two replicas on one GPU, asked alternately, each keep their
+// look-ahead.  Engines on DIFFERENT devices have nothing to share at all -- the faithful mode is "replicas only" across
+// GPUs: one process with an engine per device (the C++ testers, IPC_AMD_DEVICES).
 struct DevicePipeline {
-    ipc_engine* active = nullptr;
+    ipc_engine* active = nullptr;                      // the engine whose check ran last (matrix mode gives every pipeline of the device up)
+    std::vector<ipc_engine*> engines;                  // engines with a pipeline on this device (spec_ensure ... ipc_destroy), under run_mu
     // Held for the WHOLE of every call that reads or edits the pipeline state of an engine on this device (slots, parked
     // results, tentative states, head): a check on engine A stops the pipeline of engine B ON THE SAME DEVICE (spec_reset of
     // a FOREIGN engine), which B's owner thread may be pumping at that moment -- round 4 only guarded the pointer.  Recursive:
@@ -815,15 +818,23 @@ extern "C" int ipc_row_assignment(int n, const int* ids, int world, int policy, 
     }
     std::vector<int> lo(n), hi(n);
     for (int i = 0; i < n; ++i) { lo[i] = std::min(ids[2 * i], ids[2 * i + 1]); hi[i] = std::max(ids[2 * i], ids[2 * i + 1]); }
+    // cost[i] = own chain + sum over the overlapping pairs (i, j > i) of the union chain length.  By a sweep over the
+    // intervals sorted by first vertex: O(N log N + overlapping pairs) instead of N^2 / 2 compares (round 6: at N = 25 000
+    // -- C5 -- the all-pairs loop was ~170 ms of host time in front of the FIRST step of every (rank, world), eight times
+    // the 23 ms a rank of an 8-GPU run then solves for; the sums are the same integers, so is the assignment)
     std::vector<long long> cost(n);
-    for (int i = 0; i < n; ++i) {
-        long long c = hi[i] - lo[i];
-        const int loi = lo[i], hii = hi[i];
-        for (int j = i + 1; j < n; ++j) {
-            const int a = std::max(loi, lo[j]), b = std::min(hii, hi[j]);
-            if (b - a > 0) c += std::max(hii, hi[j]) - std::min(loi, lo[j]);
+    for (int i = 0; i < n; ++i) cost[i] = hi[i] - lo[i];
+    {
+        std::vector<int> ord(n);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return lo[a] != lo[b] ? lo[a] < lo[b] : a < b; });
+        for (int p = 0; p < n; ++p) {
+            const int a = ord[p], loa = lo[a], hia = hi[a];
+            for (int q = p + 1; q < n && lo[ord[q]] < hia; ++q) {      // (lo_b >= lo_a: the overlap is min(hi) - lo_b)
+                const int b = ord[q];
+                if (std::min(hia, hi[b]) - lo[b] > 0) cost[std::min(a, b)] += std::max(hia, hi[b]) - loa;
+            }
         }
-        cost[i] = c;
     }
     std::vector<int> rows(n);
     std::iota(rows.begin(), rows.end(), 0);
@@ -1055,6 +1066,7 @@ extern "C" int ipc_destroy(ipc_engine_t* h)
     {
         std::lock_guard<std::mutex> lk(g_pipeline_mu);
         if (dp.active == h) dp.active = nullptr;
+        dp.engines.erase(std::remove(dp.engines.begin(), dp.engines.end(), h), dp.engines.end());
     }
     free_candidates(h);
     hipFree(h->d_chain); hipFree(h->d_chain_rec); hipFree(h->d_chain_blk); hipFree(h->d_pose0); hipFree(h->d_counters); hipFree(h->d_offsets); hipFree(h->d_wave_ctr);
@@ -1261,6 +1273,13 @@ extern "C" int ipc_append_candidate(ipc_engine_t* h, const int* ids, const doubl
 static int matrix_mode_enter(ipc_engine* h, hipStream_t st)
 {
     if (!h->slots.empty() && h->spec_head >= 0) { if (int rc = spec_quiesce(h, true)) return rc; }
+    {
+        // ... and so must the pipelines of the OTHER engines of this device (round 6: they are no longer reset by each other's checks)
+        DevicePipeline& dp = device_pipeline(h->device);
+        std::lock_guard<std::recursive_mutex> run_lk(dp.run_mu);
+        for (ipc_engine* o : dp.engines)
+            if (o != h && !o->slots.empty() && o->spec_head >= 0) { if (int rc = spec_reset(o)) return rc; }
+    }
     if (h->order_stale && h->N > 0) {
         HIPCHK(hipMemcpyAsync(h->d_order, h->order.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->own_stream));
         HIPCHK(hipStreamSynchronize(h->own_stream));     // (pageable source: the copy has left the host vector when this returns)
@@ -2418,6 +2437,20 @@ static int spec_ensure(ipc_engine* h)
         // 13 ms reject on its queue.  C2 / C1 with 4 queues: 338 /s / 0.875 s with 16 slots, 398 /s / 0.700 s with 4.
         if (h->stream_concurrency * 2 <= n) h->spec_active = std::max(2, h->stream_concurrency);
     }
+    {
+        DevicePipeline& dp = device_pipeline(h->device);
+        std::lock_guard<std::recursive_mutex> lk(dp.run_mu);
+        if (std::find(dp.engines.begin(), dp.engines.end(), h) == dp.engines.end()) dp.engines.push_back(h);
+    }
+    // (a caller that never exported GPU_MAX_HW_QUEUES silently runs a quarter of the window -- say so, once)
+    if (!getenv("GPU_MAX_HW_QUEUES")) {
+        static std::once_flag warned;
+        std::call_once(warned, [&] {
+            fprintf(stderr, "[ipc_amd] GPU_MAX_HW_QUEUES is not set: the faithful mode keeps %d solves in flight instead of 16 (the HIP runtime's default is "
+                            "4 hardware queues; export GPU_MAX_HW_QUEUES=24 before the first HIP call of the process, include/ipc_amd.h \"environment\")\n",
+                    h->spec_active);
+        });
+    }
     return IPC_OK;
 }
 
@@ -2711,7 +2744,6 @@ static int spec_pump(ipc_engine* h)
         HIPCHK(h->dim == 3 ? sl.s3->fetch(o) : sl.s2->fetch(o));
         const bool aborted = h->dim == 3 ? sl.s3->aborted() : sl.s2->aborted();
         const bool lost = h->dim == 3 ? sl.s3->timed_out() : sl.s2->timed_out();
-        if (lost) ++h->persist_timeouts;
         const int p = sl.pos;
         --h->spec_states[sl.state].users;
         const bool stale = aborted || p < h->spec_head || sl.state != spec_state_at(h, p);
@@ -2760,6 +2792,17 @@ static int spec_pump(ipc_engine* h)
         n = S.pred_n;
         return S.h_pred;
     };
+    // the solves of the OTHER engines of this device that are still on the GPU (their owners are not pumping while this call
+    // holds the device's lock; a finished solve they have not collected yet no longer counts)
+    int foreign_busy = 0, foreign_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (ipc_engine* o : device_pipeline(h->device).engines) {
+        if (o == h) continue;
+        for (const ipc_engine::SpecSlot& sl : o->slots) {
+            if (sl.busy_wgs == 0 || hipEventQuery(sl.done) != hipErrorNotReady) continue;
+            foreign_busy += sl.busy_wgs;
+            for (int x = 0; x < 8; ++x) if (sl.busy_wgs > x) foreign_xcd[x] += (sl.busy_wgs - x + 7) / 8;
+        }
+    }
     int target = B;
     if (!predicting && h->accept_rate > 0.01) {
         const double r = std::log(0.05) / std::log(std::max(1e-9, 1.0 - std::min(h->accept_rate, 0.999)));
@@ -2818,6 +2861,7 @@ static int spec_pump(ipc_engine* h)
         // a CU's register file: the workgroups in flight may not exceed the CUs -- less a few, so that the copies and the
         // tail propagation of an accept (on the critical path of everything behind it) never wait for a solve to end
         for (int i = 0; i < B; ++i) if (i != q) busy += h->slots[i].busy_wgs;
+        busy += foreign_busy;
         // (an expected reject with next to nothing beside it -- a caller that appends one candidate per check -- is the critical path too)
         const bool expect_reject = (cur_pred || file_pred) && !pa && running >= 4;
         // ... and per XCD: workgroup b of a launch goes to XCD b % 8 (observed placement, MI355X guide: used for speed only -- a wrong
@@ -2830,6 +2874,7 @@ static int spec_pump(ipc_engine* h)
             for (int x = 0; x < 8; ++x) {
                 int load = 0;
                 for (int i = 0; i < B; ++i) if (i != q && h->slots[i].busy_wgs > x) load += (h->slots[i].busy_wgs - x + 7) / 8;
+                load += foreign_xcd[x];
                 gmax = std::min(gmax, 8 * std::max(0, per_xcd - load) + x);
             }
         }
@@ -2873,10 +2918,7 @@ static int agreement_check_speculative(ipc_engine* h, int k, int* agrees, ipc_ch
     DevicePipeline& dp = device_pipeline(h->device);
     std::lock_guard<std::recursive_mutex> run_lk(dp.run_mu);
     if (int rc = spec_ensure(h)) return rc;
-    if (dp.active && dp.active != h) {                  // (another engine on THIS device: its look-ahead is given up)
-        if (int rc = spec_reset(dp.active)) return rc;
-    }
-    dp.active = h;
+    dp.active = h;                                      // (other engines of this device keep their look-ahead: spec_pump's budget counts their solves)
     SpecTimer tm(h->spec_t_total);
     if (h->spec_head < 0) {                            // first call (or after a reset): the pipeline starts from the poses as they are
         if (int rc = spec_reset(h)) return rc;

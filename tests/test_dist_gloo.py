@@ -174,3 +174,44 @@ def test_row_assignment_is_a_balanced_partition():
             spread[policy] = load.max() / load.mean()
         assert spread[1] <= 1.01, spread
         assert spread[1] <= spread[0]
+
+
+def test_row_assignment_by_the_sweep_is_the_all_pairs_assignment():
+    """Round 6: the cost of a row comes from a sweep over the intervals sorted by first vertex (O(N log N + overlapping
+    pairs); the all-pairs loop was ~170 ms of host time at N = 25 000, in front of the first step of every (rank, world)).
+    The same integers, so the same greedy assignment as a numpy restatement of the round-3 rule -- on the bench's C2 list,
+    on a list of LOCAL loops (C5-like) and on random intervals with ties and touching ends."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    from ipc_amd import capi, synth
+    lib = capi.load()
+    rng = np.random.default_rng(5)
+    lists = [np.ascontiguousarray(synth.inject_outliers(synth.intel_like(), 1000, seed=1000).loop_ids, dtype=np.int32)]
+    a = rng.integers(0, 5000, 3000)
+    lists.append(np.stack([a, a + rng.integers(2, 200, 3000)], 1).astype(np.int32))
+    a = rng.integers(0, 60, 700)
+    b = a + rng.integers(1, 12, 700)
+    flip = rng.random(700) < 0.5
+    lists.append(np.where(flip[:, None], np.stack([b, a], 1), np.stack([a, b], 1)).astype(np.int32))
+    for ids in lists:
+        ids = np.ascontiguousarray(ids)
+        N = ids.shape[0]
+        lo, hi = ids.min(1).astype(np.int64), ids.max(1).astype(np.int64)
+        ov = (np.minimum(hi[:, None], hi[None, :]) - np.maximum(lo[:, None], lo[None, :])) > 0
+        union = np.maximum(hi[:, None], hi[None, :]) - np.minimum(lo[:, None], lo[None, :])
+        cost = (hi - lo) + np.triu(ov * union, k=1).sum(1)
+        for world in (2, 8):
+            rpr = lib.ipc_rows_per_rank(N, world)
+            rows = np.argsort(-cost, kind="stable")                      # costliest first, ties by index
+            load, used = np.zeros(world, dtype=np.int64), np.zeros(world, dtype=np.int64)
+            ref = np.zeros(N, dtype=np.int32)
+            for i in rows:
+                free = np.nonzero(used < rpr)[0]
+                r = free[np.argmin(load[free])]                           # least loaded rank with a free slot, ties: lower rank
+                ref[i] = r * rpr + used[r]
+                used[r] += 1
+                load[r] += cost[i]
+            slot = np.zeros(N, dtype=np.int32)
+            capi.check(lib.ipc_row_assignment(N, ids.ctypes.data_as(C.c_void_p), world, 1, slot.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(slot, ref), (N, world, np.nonzero(slot != ref)[0][:5])

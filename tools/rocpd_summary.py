@@ -21,11 +21,11 @@ def main(path):
             r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / total, r[6], r[7], r[8], r[9], r[10], r[11], r[12]))
     # The cell-solver launches of one step run on several streams and overlap (the tail of one bin
     # under the next bins), so their durations do not add up to wall time.  The figure that
-    # corresponds to bench.py's HIP-event time is the busy time of their union, per step (a step
-    # starts with two k_plan launches).
+    # corresponds to bench.py's HIP-event time is the busy time of their union, per step.
     iv = cur.execute("select start, end from kernels where name like '%_cells_kernel%' or name like '%_lds_kernel%' or name like '%_wave_kernel%' "
                      "or name like '%_group_kernel%' order by start").fetchall()
-    steps = cur.execute("select count(*) from kernels where name like 'k_plan%'").fetchone()[0] // 2
+    # one k_scatter_bits launch per step (the two k_plan launches only run in the step that builds the cell lists: round 5)
+    steps = cur.execute("select count(*) from kernels where name like 'k_scatter_bits%'").fetchone()[0]
     busy, lo, hi = 0, None, None
     for a, b in iv:
         if hi is None or a > hi:
