@@ -250,3 +250,44 @@ def test_tail_after_accepts_matches_the_serial_compose_on_long_chains(workload):
         assert np.abs(y[idx] - (y[idx - 1] + s_ * z[:, 0] + c * z[:, 1])).max() <= 2e-12 * max(extent, 1.0)
         assert np.abs(np.angle(np.exp(1j * (th[idx] - th[idx - 1] - z[:, 2])))).max() <= 1e-12
     eng.close()
+
+
+# ---- resume from a saved state (ipc_incremental_set_state, round 6) -----------------------------------------------------
+@pytest.mark.parametrize("workload", ["C1", "C4s"])
+def test_a_run_resumed_from_a_saved_state_continues_as_the_uninterrupted_run(workload):
+    """The state of the reference's IPC object is the vertex estimates + _max_consensus_set (include/ipc/consensus.hpp:23-32):
+    (ipc_current_poses, ipc_consensus_set) taken in the middle of a run and handed to ANOTHER engine continue that run --
+    SE3 bit for bit (the rotation matrices are the state), SE2 to rounding (cos / sin of theta are recomputed).  Bad
+    arguments are refused."""
+    import bench
+    from ipc_amd import capi
+    from ipc_amd.consensus import IPC
+    g, cfg, _ = bench.build_workload(workload)
+    a, b = IPC(g, cfg, device=0), IPC(g, cfg, device=0)
+    order = a.candidate_order()
+    cut = len(order) // 2
+    a.reset()
+    ra = []
+    for q, k in enumerate(order):
+        if q == cut:
+            b.set_state(a.current_poses(), a.getMaxConsensusSet(), cut)
+            assert np.array_equal(b.getMaxConsensusSet(), a.getMaxConsensusSet())
+        ok, info = a.agreementCheck(int(k), with_info=True)
+        ra.append((ok, info.lo, info.hi, info.n_cluster_loops, info.max_chi2))
+    assert sum(r[0] for r in ra[:cut]) >= 5
+    for q in range(cut, len(order)):
+        ok, info = b.agreementCheck(int(order[q]), with_info=True)
+        r = ra[q]
+        assert (ok, info.lo, info.hi, info.n_cluster_loops) == r[:4], q
+        if g.dim == 3:
+            assert np.float64(info.max_chi2).tobytes() == np.float64(r[4]).tobytes(), (q, info.max_chi2, r[4])
+        else:
+            assert abs(info.max_chi2 - r[4]) <= 1e-6 * max(abs(r[4]), 1e-12), (q, info.max_chi2, r[4])    # (the dog-leg's last steps are rounding-driven)
+    assert np.array_equal(a.getMaxConsensusSet(), b.getMaxConsensusSet())
+    pa, pb = a.current_poses(), b.current_poses()
+    assert np.abs(pa - pb).max() <= (0.0 if g.dim == 3 else 1e-7)
+    with pytest.raises(capi.IpcError):
+        b.set_state(pa, np.array([g.N + 3], dtype=np.int32), 0)            # not a candidate
+    with pytest.raises(capi.IpcError):
+        b.set_state(pa, a.getMaxConsensusSet(), g.N + 1)                    # resume position beyond the list
+    a.close(); b.close()

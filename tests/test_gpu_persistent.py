@@ -626,10 +626,11 @@ def test_a_nan_edge_does_not_mask_an_edge_above_the_threshold(oracle):
 
 
 def test_two_threads_with_an_engine_each_run_their_faithful_loops_side_by_side():
-    """Round 5 (ADVICE): a check on one engine stops the pipeline of the other (one pipeline per process), which the other
-    engine's owner thread may be pumping at that very moment.  Every call that touches pipeline state now holds one
-    process-wide lock for its whole duration: two threads that interleave their checks get, each, exactly the records of a
-    run on its own -- no lost candidate, no recycled tentative state."""
+    """Round 5 (ADVICE): a check on one engine could stop the pipeline of the other, which the other engine's owner thread may be
+    pumping at that very moment.  Every call that touches pipeline state holds one lock PER DEVICE (round 6; process-wide in
+    round 5) for its whole duration, and since round 6 the engines of a device no longer reset each other at all (they share
+    the device's workgroup budget): two threads that interleave their checks get, each, exactly the records of a run on its
+    own -- no lost candidate, no recycled tentative state."""
     import threading
     import bench
     g, cfg, _ = bench.build_workload("tiny")
