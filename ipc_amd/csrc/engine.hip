@@ -2797,8 +2797,11 @@ static int spec_pump(ipc_engine* h)
     int foreign_busy = 0, foreign_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (ipc_engine* o : device_pipeline(h->device).engines) {
         if (o == h) continue;
-        for (const ipc_engine::SpecSlot& sl : o->slots) {
-            if (sl.busy_wgs == 0 || hipEventQuery(sl.done) != hipErrorNotReady) continue;
+        for (ipc_engine::SpecSlot& sl : o->slots) {
+            if (sl.busy_wgs == 0) continue;
+            // (a finished solve is asked about ONCE: its owner still collects it by sl.cand -- with dozens of idle engines alive, as
+            // in the test suite's process, sixteen event queries per engine and pump made the host loop the bottleneck: 9.3 s for C2)
+            if (hipEventQuery(sl.done) != hipErrorNotReady) { sl.busy_wgs = 0; continue; }
             foreign_busy += sl.busy_wgs;
             for (int x = 0; x < 8; ++x) if (sl.busy_wgs > x) foreign_xcd[x] += (sl.busy_wgs - x + 7) / 8;
         }
@@ -2903,7 +2906,7 @@ static int spec_pump(ipc_engine* h)
 static int spec_reset(ipc_engine* h)
 {
     for (size_t q = 0; q < h->slots.size(); ++q) spec_abort_slot(h, (int)q);
-    for (auto& sl : h->slots) HIPCHK(hipStreamSynchronize(sl.st));
+    for (auto& sl : h->slots) { HIPCHK(hipStreamSynchronize(sl.st)); sl.busy_wgs = 0; }      // (nothing of this engine is on the GPU any more)
     if (h->pred_stream) HIPCHK(hipStreamSynchronize(h->pred_stream));      // (the prediction kernels read the candidates and the states' poses)
     for (auto& R : h->spec_res) R.valid = false;
     for (int t : h->tent) h->spec_states[t].live = false;

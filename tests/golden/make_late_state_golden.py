@@ -230,7 +230,12 @@ def main():
         for i, q in enumerate(pos):
             nxt = pos[i + 1] if i + 1 < len(pos) else n
             jobs.append((a.tag, i, min(nxt, q + a.forward)))
-        jobs.sort(key=lambda j: -(j[2] - (pos[j[1]] if j[1] >= 0 else 0)))
+        # (a stretch whose every position already has a record -- an earlier, interrupted invocation -- is not run again)
+        fpath = os.path.join(ROOT, "gpurun_out", "late_forward_%s.jsonl" % a.tag)
+        have = set(json.loads(line)["q"] for line in open(fpath)) if os.path.exists(fpath) else set()
+        first = lambda j: pos[j[1]] if j[1] >= 0 else len(np.load(exp)["order"])
+        jobs = [j for j in jobs if any(q not in have for q in range(first(j), j[2]))]
+        jobs.sort(key=lambda j: -(j[2] - first(j)))
         print("%s: %d forward stretches on %d workers" % (a.tag, len(jobs), a.workers), flush=True)
         from multiprocessing import Pool
         with Pool(a.workers) as pool:
