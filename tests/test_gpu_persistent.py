@@ -740,3 +740,39 @@ def test_two_engines_on_one_device_keep_their_look_ahead():
     _assert_bitwise(ra, rb)
     print("\n[two engines on one device, C2] alone %.3f s + %.3f s, alternately %.3f s (x %.2f)" % (ta, tb, best, best / (ta + tb)))
     assert best <= 1.15 * (ta + tb), (ta, tb, best)
+
+
+@pytest.mark.parametrize("mode", ["persist", "host"])
+def test_levenberg_retry_through_the_banded_literal_system_se2(oracle, mode):
+    """Round 6: the Levenberg retry factors g2o's literal normal equations in the banded + bordered layout
+    (cluster_literal_band.hpp) -- here its SE2 instance, forced onto a small spiral (IPC_LITERAL_BAND_MIN_N=0: every damped
+    solve whose loops form a band): 300 poses closed onto the turn before (span 25) + a few wide outliers that go to the border,
+    three odometry edges without rotational information and one with none at all.  The whole faithful run against the oracle:
+    decisions equal, chi2 within 1e-5, and the banded path was really taken."""
+    from ipc_amd import synth
+    from ipc_amd.consensus import Config
+    O = oracle
+    g = synth.inject_outliers(synth.ring_se2(seed=5, V=300, per_ring=25), 12, seed=8)
+    g = g.subset(np.concatenate([np.arange(0, 275, 3), np.arange(275, g.N)]))
+    oi = g.odom_info.copy()
+    for e in (40, 120, 201):
+        oi[e] = [oi[e][0], 0.0, 0.0, oi[e][3], 0.0, 0.0]
+    oi[160] = 0.0
+    g.odom_info = oi
+    cfg = Config()
+    eng = _engine(g, cfg, mode, IPC_LITERAL_BAND_MIN_N=0)
+    inc = O.IncrementalIPC(2, g.odom_meas, g.odom_info, cfg.s_factor, cfg.fast_reject_th, cfg.fast_reject_iter_base,
+                           cfg.slow_reject_th, cfg.slow_reject_iter_base, g.loop_ids, g.loop_meas, g.loop_info)
+    eng.reset()
+    damped = 0
+    for k in eng.candidate_order():
+        ok_ref, ref = inc.agreement_check(int(k))
+        ok, info = eng.agreementCheck(int(k), with_info=True)
+        assert ok == ok_ref, (k, ref, info.max_chi2)
+        if info.flags & 1:                               # (a solve cut off by the iteration cap stops on a path-dependent point)
+            assert abs(info.max_chi2 - ref["max_chi2"]) <= REL * max(abs(ref["max_chi2"]), 1e-9), (k, ref, info.max_chi2)
+        assert not (info.flags & 2)
+        damped += bool(info.flags & 4)
+    c = eng.incremental_counters()
+    assert damped > 0 and c["literal_band_solves"] > 0, (damped, c)
+    assert np.array_equal(eng.getMaxConsensusSet(), inc.consensus())
